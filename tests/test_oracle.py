@@ -1,0 +1,281 @@
+"""CPU tests: the oracle against the reference-produced golden vectors
+(tests/golden/, made by tests/golden/make_golden.py from the reference's own
+Python twin), against the independent numpy restatement, and against analytic
+known answers."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from oracle import ekf_np
+
+PSETS = ["pydefault", "rotors400", "hardware", "nobias"]
+
+
+def load_param_sets(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "param_sets.json")))
+
+
+def orc_params_for(ps, sets, **over):
+    s = sets[ps]
+    q = s["Q"]
+    kw = dict(update_freq=s["update_freq"], est_bias=int(s["est_bias"]), direct_orien_method=1,
+              Q_a=q[0:3], Q_w=q[3:6], R_r=s["R"][0:3], R_ang=s["R"][3:6], r_v_cv=s["r_v_cv"], q_vc=s["q_vc"])
+    if s["est_bias"]:
+        kw.update(Q_ab=q[6:9], Q_wb=q[9:12])
+    kw.update(over)
+    return oracle.make_params(**kw)
+
+
+def qclose(a, b, tol):
+    a = np.asarray(a); b = np.asarray(b)
+    return min(np.abs(a - b).max(), np.abs(a + b).max()) < tol
+
+
+# ------------------------------------------------------------------ helpers
+def test_helper_kats(golden_dir):
+    kat = json.load(open(os.path.join(golden_dir, "kat.json")))
+    for c in kat["skew_symm"]:
+        np.testing.assert_array_equal(oracle.skew_symm(c["in"]), np.array(c["out"]))
+    for c in kat["quaternion_norm"]:
+        np.testing.assert_allclose(oracle.quaternion_norm(c["in"]), c["out"], rtol=0, atol=1e-15)
+    for c in kat["quaternion_exp"]:
+        # C++ normalises inside quaternion_exp (QH.cpp:30), the Python twin does not: rounding-level only
+        np.testing.assert_allclose(oracle.quaternion_exp(c["in"]), c["out"], rtol=0, atol=1e-15)
+        np.testing.assert_allclose(ekf_np.quaternion_exp(c["in"]), c["out"], rtol=0, atol=1e-15)
+    for c in kat["quaternion_log"]:
+        np.testing.assert_allclose(oracle.quaternion_log(c["in"]), c["out"], rtol=1e-14, atol=1e-16)
+        np.testing.assert_allclose(ekf_np.quaternion_log(c["in"]), c["out"], rtol=1e-14, atol=1e-16)
+
+
+def test_survey_appendix_c_literals():
+    """Numbers captured in SURVEY.md Appendix C (reference Python twin)."""
+    np.testing.assert_allclose(oracle.quaternion_exp([0.1, 0.2, 0.3]),
+                               [0.04970884332485948, 0.09941768664971896, 0.14912652997457843, 0.9825509821552589], atol=1e-15)
+    q = np.array([0.1, 0.2, 0.3, 0.9]); q /= np.linalg.norm(q)
+    np.testing.assert_allclose(oracle.quaternion_log(q), [0.21060240739016323, 0.42120481478032645, 0.6318072221704897], atol=1e-15)
+    np.testing.assert_array_equal(oracle.quaternion_norm([0, 0, 0.6, -0.8]), [-0.0, -0.0, -0.6, 0.8])
+    np.testing.assert_array_equal(oracle.quaternion_norm([0, 0, 0.8, -0.6]), [0, 0, 0.8, -0.6])
+    p = oracle.make_params(direct_orien_method=1)
+    x = [0.3, -0.2, 2.0, 0.1, 0.0, -0.05, 0, 0, 0, 1] + [0.0] * 6
+    P0 = np.diag([0.1] * 3 + [0.1] * 3 + [0.15] * 3 + [0.5] * 3 + [0.1] * 3)
+    xc, Pc, acc = oracle.prediction_step(p, x, P0, [0.2, -0.1, 9.9, 0.05, -0.02, 0.3])
+    np.testing.assert_allclose(xc[:10], [0.301, -0.2, 1.9995, 0.10200000000000001, -0.001, -0.04900000000000001,
+                                         0.0002499999032291779, -9.999996129167116e-05, 0.0014999994193750673,
+                                         0.9999988387502248], rtol=0, atol=2e-16)
+    assert abs(np.linalg.norm(Pc) - 0.9554539418248377) < 1e-15
+    assert abs(np.trace(Pc) - 2.8698167999999997) < 1e-14
+    assert abs(Pc.sum() - 2.839957049839766) < 1e-14
+    q_ct = np.array([0.7, -0.71, 0.02, 0.01]); q_ct /= np.linalg.norm(q_ct)
+    xh, Ph, _, _ = oracle.correction_step(p, xc, Pc, [0.21, 0.33, 1.93], q_ct)
+    np.testing.assert_allclose(xh, [0.2517276634781874, 0.17191972616426188, 2.0064899738410977, 0.09916861501951421,
+                                    0.0038253092905989727, -0.04887168396119881, -0.0057461154909256565,
+                                    -0.01176145238791947, -0.01680690870427726, 0.999773063357029, 0, 0, 0,
+                                    7.993998189018213e-05, 0.00015491368551940671, 0.00024323407625875424], rtol=0, atol=5e-15)
+    assert abs(np.linalg.norm(Ph) - 0.9025469084945956) < 1e-14
+    assert abs(np.trace(Ph) - 2.1818996943402444) < 1e-14
+
+
+# ----------------------------------------------------- golden step vectors
+@pytest.mark.parametrize("ps", PSETS)
+def test_predict_golden(golden_dir, ps):
+    sets = load_param_sets(golden_dir)
+    d = np.load(os.path.join(golden_dir, "predict_cases.npz"))
+    p = orc_params_for(ps, sets)
+    pn = ekf_np.Params.from_orc(p)
+    for i in range(d[f"{ps}__x"].shape[0]):
+        x, P, u = d[f"{ps}__x"][i], d[f"{ps}__P"][i], d[f"{ps}__u"][i]
+        for impl in (lambda: oracle.prediction_step(p, x, P, u), lambda: ekf_np.prediction_step(pn, x, P, u)):
+            xc, Pc, acc = impl()
+            np.testing.assert_allclose(xc, d[f"{ps}__x_check"][i], rtol=1e-13, atol=1e-14)
+            np.testing.assert_allclose(Pc, d[f"{ps}__P_check"][i], rtol=1e-12, atol=1e-15)
+            np.testing.assert_allclose(acc, d[f"{ps}__accel"][i], rtol=1e-13, atol=1e-13)
+
+
+@pytest.mark.parametrize("ps", PSETS)
+def test_update_golden(golden_dir, ps):
+    sets = load_param_sets(golden_dir)
+    d = np.load(os.path.join(golden_dir, "update_cases.npz"))
+    p = orc_params_for(ps, sets)
+    pn = ekf_np.Params.from_orc(p)
+    for i in range(d[f"{ps}__x"].shape[0]):
+        x, P, z = d[f"{ps}__x"][i], d[f"{ps}__P"][i], d[f"{ps}__z"][i]
+        for impl in (lambda: oracle.correction_step(p, x, P, z[:3], z[3:]), lambda: ekf_np.correction_step(pn, x, P, z[:3], z[3:])):
+            xh, Ph = impl()[:2]
+            np.testing.assert_allclose(xh, d[f"{ps}__x_hat"][i], rtol=1e-11, atol=1e-12)
+            np.testing.assert_allclose(Ph, d[f"{ps}__P_hat"][i], rtol=1e-10, atol=1e-13)
+
+
+@pytest.mark.parametrize("ps", PSETS)
+def test_sequence_golden(golden_dir, ps):
+    """Single-rate tick loop (EKF.cpp:238-249, 265-290) over hundreds of ticks."""
+    sets = load_param_sets(golden_dir)
+    d = np.load(os.path.join(golden_dir, "sequence_cases.npz"))
+    p = orc_params_for(ps, sets)
+    n = p.num_states
+    U, Z, M = d[f"{ps}__u"], d[f"{ps}__z"], d[f"{ps}__mask"]
+    x = d[f"{ps}__x_init"].copy(); P = d[f"{ps}__P_init"].copy()
+    full = dict(zip(d[f"{ps}__P_full_ticks"].tolist(), d[f"{ps}__P_full"]))
+    for t in range(U.shape[0]):
+        x, P, _ = oracle.prediction_step(p, x, P, U[t])
+        if M[t]:
+            x, P = oracle.correction_step(p, x, P, Z[t, :3], Z[t, 3:])[:2]
+        np.testing.assert_allclose(x, d[f"{ps}__x_seq"][t], rtol=1e-9, atol=1e-10)
+        np.testing.assert_allclose(np.diag(P), d[f"{ps}__P_diag_seq"][t], rtol=1e-9, atol=1e-13)
+        if t in full:
+            np.testing.assert_allclose(P, full[t], rtol=1e-8, atol=1e-12)
+    # batch runner reproduces the same final state
+    xb, Pb = oracle.run_batch(p, d[f"{ps}__x_init"][None], d[f"{ps}__P_init"][None], U[:, None, :], Z[:, None, :], M[:, None])
+    np.testing.assert_allclose(xb[0], x, rtol=0, atol=0)
+    np.testing.assert_allclose(Pb[0], P, rtol=0, atol=0)
+    assert n == P.shape[0]
+
+
+# --------------------------------------- C++-only branches: C vs numpy only
+def rand_case(rng, n):
+    x = np.zeros(16)
+    x[0:3] = rng.uniform([-1, -1, 1], [1, 1, 4]); x[3:6] = rng.normal(size=3) * 0.5
+    q = rng.normal(size=4); q /= np.linalg.norm(q); x[6:10] = q if q[3] > 0 else -q
+    if n == 15:
+        x[10:13] = rng.normal(size=3) * 0.1; x[13:16] = rng.normal(size=3) * 0.01
+    A = rng.normal(size=(n, n)) * 0.1
+    P = A @ A.T + np.diag(rng.uniform(0.01, 0.2, size=n))
+    return x, 0.5 * (P + P.T)
+
+
+@pytest.mark.parametrize("direct", [0, 1])
+@pytest.mark.parametrize("est_bias", [0, 1])
+def test_c_vs_numpy_all_branches(direct, est_bias):
+    rng = np.random.default_rng(7 + 2 * direct + est_bias)
+    p = oracle.make_params(direct_orien_method=direct, est_bias=est_bias, ab_static=[0.2, -0.09, -0.03],
+                           wb_static=[-0.02, -0.01, 0.0], r_v_cv=[0.06036412, -0.00145196, -0.04439579],
+                           q_vc=[-0.7035177, 0.7106742, 0.0014521, -0.0017207], update_freq=400.0)
+    pn = ekf_np.Params.from_orc(p)
+    n = p.num_states
+    for i in range(40):
+        x, P = rand_case(rng, n)
+        u = np.append(rng.normal(size=3) * 1.5 + [0, 0, 9.8], rng.normal(size=3) * 0.4)
+        a = oracle.prediction_step(p, x, P, u); b = ekf_np.prediction_step(pn, x, P, u)
+        for s, t in zip(a, b):
+            np.testing.assert_allclose(s, t, rtol=1e-12, atol=1e-14)
+        # measurement near the state; includes cases where the delta_q flip fires (i % 7 == 0)
+        ang = 3.0 if i % 7 == 0 else 0.8
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+        dq = np.append(ax * math.sin(ang / 2), math.cos(ang / 2))
+        q_true = ekf_np.qmul(x[6:10], dq)
+        r_true = x[0:3] + rng.normal(size=3) * 0.1
+        q_ct = ekf_np.qmul(ekf_np.qconj(pn.q_vc), ekf_np.qconj(q_true))
+        r_c = pn.C_vc.T @ (-ekf_np.rot(q_true).T @ r_true - pn.r_v_cv)
+        a = oracle.correction_step(p, x, P, r_c, q_ct); b = ekf_np.correction_step(pn, x, P, r_c, q_ct)
+        assert qclose(a[0][6:10], b[0][6:10], 1e-11)
+        np.testing.assert_allclose(np.delete(a[0], range(6, 10)), np.delete(b[0], range(6, 10)), rtol=1e-10, atol=1e-11)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-9, atol=1e-12)
+        np.testing.assert_allclose(a[2], b[2], rtol=1e-12, atol=1e-13)
+        # observation model inverts: r_obs is the true position, q_obs the true attitude (direct method)
+        if direct:
+            np.testing.assert_allclose(a[2], r_true, atol=1e-12)
+        assert qclose(a[3], q_true, 1e-12)
+        np.testing.assert_allclose(oracle.seed_pose(p, r_c, q_ct)[0], ekf_np.seed_pose(pn, r_c, q_ct)[0], atol=1e-13)
+
+
+def test_corner_gate_c_vs_numpy():
+    rng = np.random.default_rng(11)
+    hw_w = [0.08382] + [0.16764] * 4 + [0.33528] * 4 + [0.16764] * 4
+    hw_p = [0, 0, 0, 0, 0.1571625, 0, 0.1571625, 0, 0, 0, -0.1571625, 0, -0.1571625, 0, 0, -0.244475, 0.244475, 0,
+            0.244475, 0.244475, 0, 0.244475, -0.244475, 0, -0.244475, -0.244475, 0, 0, 0.314325, 0, 0.314325, 0, 0,
+            0, -0.314325, 0, -0.314325, 0, 0]
+    sets = [oracle.make_params(),
+            oracle.make_params(n_tags=13, tag_in_view_margin=0.0, tag_widths=hw_w, tag_positions=hw_p,
+                               camera_K=[437.3412312213781, 0, 328.5442810236917, 0, 438.0867474272743, 239.2536470406629, 0, 0, 1],
+                               camera_width=640, camera_height=480)]
+    seen = set()
+    for p in sets:
+        pn = ekf_np.Params.from_orc(p)
+        for _ in range(300):
+            r = rng.uniform([-2.5, -1.5, 0.3], [2.5, 1.5, 4.0])
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 0.6)
+            q = np.append(ax * math.sin(ang / 2), math.cos(ang / 2))
+            a = oracle.corner_gate(p, r, q); b = ekf_np.corner_gate(pn, r, q)
+            assert a == b
+            seen.add(a)
+    assert seen == {0, 1}
+
+
+# ------------------------------------------------------------ analytic KATs
+def test_hover_and_constant_yaw_rate():
+    p = oracle.make_params()
+    x = np.zeros(16); x[2] = 2.0; x[3:6] = [0.1, -0.2, 0.05]; x[9] = 1.0
+    P = np.diag(list(p.cov_init))
+    # hover: a_meas = C^T(-g), w = 0 -> v constant, q constant
+    xc, Pc, acc = oracle.prediction_step(p, x, P, [0, 0, 9.8, 0, 0, 0])
+    np.testing.assert_allclose(acc, 0, atol=1e-15)
+    np.testing.assert_allclose(xc[3:6], x[3:6], atol=1e-16)
+    np.testing.assert_array_equal(xc[6:10], x[6:10])
+    np.testing.assert_allclose(xc[0:3], x[0:3] + 0.01 * x[3:6], atol=1e-16)
+    # closed-form covariance from a diagonal P
+    dT = p.dT_nom
+    np.testing.assert_allclose(np.diag(Pc)[0:3], 0.1 + dT * dT * 0.1, rtol=1e-14)
+    np.testing.assert_allclose(np.diag(Pc)[6:9], 0.15 + dT * dT * 0.1 + 0.0005, rtol=1e-14)
+    np.testing.assert_allclose(np.diag(Pc)[9:12], 0.5 + 5e-5, rtol=1e-14)
+    # constant yaw rate: q_N = exp(N dT w)
+    w = np.array([0, 0, 0.7]); N = 200
+    for _ in range(N):
+        x, P, _ = oracle.prediction_step(p, x, P, [0, 0, 9.8, *w])
+    assert qclose(x[6:10], oracle.quaternion_exp(N * dT * w), 1e-13)
+
+
+def test_exp_log_roundtrip_and_zero_innovation():
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        v = rng.normal(size=3) * rng.choice([1e-6, 0.1, 1.0])
+        np.testing.assert_allclose(oracle.quaternion_log(oracle.quaternion_exp(v)), v, rtol=1e-12, atol=1e-18)
+    for direct in (0, 1):
+        p = oracle.make_params(direct_orien_method=direct)
+        pn = ekf_np.Params.from_orc(p)
+        x, P = rand_case(rng, 15)
+        q_ct = ekf_np.qmul(ekf_np.qconj(pn.q_vc), ekf_np.qconj(x[6:10]))
+        r_c = pn.C_vc.T @ (-ekf_np.rot(x[6:10]).T @ x[0:3] - pn.r_v_cv)
+        xh, Ph, _, _ = oracle.correction_step(p, x, P, r_c, q_ct)
+        np.testing.assert_allclose(xh, x, atol=1e-12)
+        ev = np.linalg.eigvalsh(0.5 * (Ph + Ph.T))
+        assert ev.min() > 0
+        assert np.linalg.eigvalsh(P - 0.5 * (Ph + Ph.T)).min() > -1e-12  # P_hat <= P_check
+        assert np.abs(Ph - Ph.T).max() < 1e-14
+
+
+def test_initialize_params_derived():
+    p = oracle.make_params(update_freq=400.0, measurement_freq=30.0, measurement_delay=0.030)
+    assert p.upd_per_meas == 14 and p.num_states == 15 and abs(p.dT_nom - 0.0025) < 1e-18
+    assert p.measurement_step_delay == 12
+    p = oracle.make_params(update_freq=100.0, measurement_freq=15.0, est_bias=0)
+    assert p.upd_per_meas == 7 and p.num_states == 9
+    np.testing.assert_allclose(np.array(list(p.C_vc)).reshape(3, 3), [[0, -1, 0], [-1, 0, 0], [0, 0, -1]], atol=1e-15)
+
+
+def test_filter_update_single_rate_matches_manual_loop(golden_dir):
+    """orc_filter_update (EKF.cpp:127-303) with rate limiting reproduces the golden sequence."""
+    sets = load_param_sets(golden_dir)
+    d = np.load(os.path.join(golden_dir, "sequence_cases.npz"))
+    ps = "pydefault"
+    p = orc_params_for(ps, sets, measurement_freq=15.0, limit_measurement_freq=1, corner_margin_enbl=0)
+    assert p.upd_per_meas == 7
+    U, Z, M = d[f"{ps}__u"], d[f"{ps}__z"], d[f"{ps}__mask"]
+    f = oracle.Filter(p)
+    # seed directly from the golden initial state
+    x0 = d[f"{ps}__x_init"]
+    for i in range(3):
+        f.f.r_nom[i] = x0[i]; f.f.v_nom[i] = x0[3 + i]; f.f.ab_nom[i] = x0[10 + i]; f.f.wb_nom[i] = x0[13 + i]
+    for i in range(4):
+        f.f.q_nom[i] = x0[6 + i]
+    f.f.state_initialized = 1
+    for t in range(U.shape[0]):
+        f.set_imu(U[t, :3], U[t, 3:])
+        if M[t]:
+            f.set_apriltag(Z[t, :3], Z[t, 3:], t * 0.01)
+        f.filter_update(t * 0.01)
+        assert f.f.performed_correction == int(M[t])
+        np.testing.assert_allclose(f.x(), d[f"{ps}__x_seq"][t], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(np.diag(f.P()), d[f"{ps}__P_diag_seq"][-1], rtol=1e-9)
