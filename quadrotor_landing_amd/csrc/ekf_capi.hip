@@ -1,0 +1,813 @@
+// ekf_capi.hip -- C-ABI (include/qle_ekf.h) over the HIP kernels.
+// Host side of the batched relative-pose EKF engine: handle and device-memory
+// management, parameter derivation (initialize_params, EKF.cpp:87-125 of the
+// reference), AoS<->quad-row staging, launches on the handle's own stream.
+// There is deliberately no CPU compute path in this file.
+#include "../../include/qle_ekf.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "ekf_kernels.hpp"
+#include "synth_kernels.hpp"
+
+using namespace qle;
+
+// ------------------------------------------------------------------ errors
+static thread_local std::string g_err;
+
+static int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return fail(QLE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+#define QLE_TRY(expr)            \
+    do {                         \
+        int rc_ = (expr);        \
+        if (rc_ != QLE_OK) return rc_; \
+    } while (0)
+
+extern "C" const char* qle_last_error(void) { return g_err.c_str(); }
+extern "C" const char* qle_version(void) { return "quadrotor_landing_amd 0.1 (gfx950)"; }
+
+extern "C" int qle_device_count(int32_t* count)
+{
+    if (!count) return fail(QLE_ERR_INVALID, "count is null");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) { *count = 0; return fail(QLE_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    *count = n;
+    return QLE_OK;
+}
+
+// -------------------------------------------------------------- parameters
+extern "C" int qle_params_default(qle_params* p)
+{   // RelativePoseEKF::RelativePoseEKF(), EKF.cpp:28-81; cov_init from NODE.cpp:89-93
+    if (!p) return fail(QLE_ERR_INVALID, "params is null");
+    std::memset(p, 0, sizeof(*p));
+    p->update_freq = 100.0;
+    p->measurement_freq = 10.0;
+    p->measurement_delay = 0.010;
+    p->measurement_delay_max = 0.200;
+    p->dyn_measurement_delay_offset = 0.0;
+    p->est_bias = 1;
+    p->limit_measurement_freq = 0;
+    p->corner_margin_enbl = 1;
+    p->direct_orien_method = 0;
+    p->multirate_ekf = 0;
+    p->dynamic_meas_delay = 0;
+    p->r_cov_init = 0.1; p->v_cov_init = 0.1; p->ang_cov_init = 0.15; p->ab_cov_init = 0.5; p->wb_cov_init = 0.1;
+    for (int i = 0; i < 3; ++i) { p->Q_a[i] = 0.005; p->Q_w[i] = 0.0005; p->Q_ab[i] = 5E-5; p->Q_wb[i] = 5E-6; }
+    p->R_r[0] = 0.005; p->R_r[1] = 0.005; p->R_r[2] = 0.015;
+    p->R_ang[0] = 0.0025; p->R_ang[1] = 0.0025; p->R_ang[2] = 0.025;
+    p->r_v_cv[2] = -0.073;
+    p->q_vc[0] = 0.70711; p->q_vc[1] = -0.70711;  // Quaterniond(w=0, x=0.70711, y=-0.70711, z=0), EKF.cpp:56
+    p->camera_K[0] = 241.4268; p->camera_K[2] = 376.5; p->camera_K[4] = 241.4268; p->camera_K[5] = 240.5; p->camera_K[8] = 1.0;
+    p->camera_width = 752; p->camera_height = 480;
+    p->n_tags = 1;
+    p->tag_in_view_margin = 0.02;
+    p->tag_widths[0] = 0.8;
+    p->small_ang_tol = 1E-10;
+    p->g[2] = -9.8;
+    return QLE_OK;
+}
+
+extern "C" int qle_params_derive(const qle_params* p, qle_derived* d)
+{   // RelativePoseEKF::initialize_params(), EKF.cpp:87-125
+    if (!p || !d) return fail(QLE_ERR_INVALID, "null argument");
+    if (!(p->update_freq > 0.0) || !(p->measurement_freq > 0.0)) return fail(QLE_ERR_INVALID, "update_freq and measurement_freq must be > 0");
+    if (p->n_tags < 0 || p->n_tags > QLE_MAX_TAGS) return fail(QLE_ERR_INVALID, "n_tags out of range [0,%d]", QLE_MAX_TAGS);
+    std::memset(d, 0, sizeof(*d));
+    d->dT_nom = 1.0 / p->update_freq;                                               // :90
+    d->upd_per_meas = (int32_t)std::ceil(p->update_freq / p->measurement_freq);     // :91
+    d->num_states = p->est_bias ? 15 : 9;                                           // :92
+    d->measurement_step_delay = std::max((int32_t)(p->measurement_delay / d->dT_nom + 0.5), 1);  // :93
+    for (int i = 0; i < 3; ++i) {
+        d->Q[i] = p->Q_a[i];
+        d->Q[3 + i] = p->Q_w[i];
+        d->cov_init[i] = p->r_cov_init;
+        d->cov_init[3 + i] = p->v_cov_init;
+        d->cov_init[6 + i] = p->ang_cov_init;
+        if (p->est_bias) {
+            d->Q[6 + i] = p->Q_ab[i];
+            d->Q[9 + i] = p->Q_wb[i];
+            d->cov_init[9 + i] = p->ab_cov_init;
+            d->cov_init[12 + i] = p->wb_cov_init;
+        }
+        d->R[i] = p->R_r[i];
+        d->R[3 + i] = p->R_ang[i];
+    }
+    // quaternion_norm(q_vc) (:121, QH.cpp:61-73) and C_vc = q_vc.toRotationMatrix() (:122)
+    double n = std::sqrt(p->q_vc[0] * p->q_vc[0] + p->q_vc[1] * p->q_vc[1] + p->q_vc[2] * p->q_vc[2] + p->q_vc[3] * p->q_vc[3]);
+    if (!(n > 0.0)) return fail(QLE_ERR_INVALID, "q_vc has zero norm");
+    for (int i = 0; i < 4; ++i) d->q_vc[i] = p->q_vc[i] / n;
+    if (d->q_vc[3] < -0.75)
+        for (int i = 0; i < 4; ++i) d->q_vc[i] = -d->q_vc[i];
+    const double x = d->q_vc[0], y = d->q_vc[1], z = d->q_vc[2], w = d->q_vc[3];
+    double* C = d->C_vc;
+    C[0] = 1 - 2 * (y * y + z * z); C[1] = 2 * (x * y - w * z);     C[2] = 2 * (x * z + w * y);
+    C[3] = 2 * (x * y + w * z);     C[4] = 1 - 2 * (x * x + z * z); C[5] = 2 * (y * z - w * x);
+    C[6] = 2 * (x * z - w * y);     C[7] = 2 * (y * z + w * x);     C[8] = 1 - 2 * (x * x + y * y);
+    return QLE_OK;
+}
+
+// ------------------------------------------------------------------ handle
+struct qle_batch {
+    int64_t B = 0;
+    int32_t dtype = QLE_F32;
+    int32_t device = 0;
+    int32_t block = 64;
+    size_t wsz = 4;
+    qle_params pub;
+    qle_derived der;
+    DevParams<float> pf;
+    DevParams<double> pd;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    void* x = nullptr;     // [16 words] quad rows
+    void* P = nullptr;     // [120 words] quad rows
+    void* pfp = nullptr;   // [24 words] quad rows, per-filter params
+    bool pfp_on = false;
+    bool aux = false;
+    void* aux_accel = nullptr;  // AoS [B][3], compute dtype
+    void* aux_obs = nullptr;    // AoS [B][7]
+    void* tick_u = nullptr;     // one tick of inputs in device layout
+    void* tick_z = nullptr;
+    double* stage = nullptr;    // AoS fp64 staging, kStageFilters filters
+    uint8_t* stage_mask = nullptr;
+    unsigned long long* counter = nullptr;
+    bool state_set = false;
+};
+
+struct qle_inputs {
+    qle_batch* h = nullptr;
+    int64_t T = 0;
+    int64_t n_slots = 0;
+    std::vector<int32_t> slot;  // per tick: measurement slot or -1
+    size_t pitch_u = 0, pitch_z = 0;
+    void* u = nullptr;
+    void* z = nullptr;
+    void* truth = nullptr;      // AoS [B][7] fp64: r(3), q(4) at the end of the sequence
+    void* truth_bias = nullptr; // AoS [B][6] fp64
+    bool has_truth = false;
+};
+
+static constexpr int64_t kStageFilters = 32768;
+static constexpr int64_t kStageDoubles = kStageFilters * 225;
+
+template <typename T> static DevParams<T> make_dev(const qle_params& p, const qle_derived& d)
+{
+    DevParams<T> o;
+    o.dT = (T)d.dT_nom;
+    o.dTw = p.est_bias ? (T)d.dT_nom : T(0);
+    o.bias_on = p.est_bias ? T(1) : T(0);
+    o.small_ang_tol = (T)p.small_ang_tol;
+    for (int i = 0; i < 3; ++i) { o.g[i] = (T)p.g[i]; o.r_v_cv[i] = (T)p.r_v_cv[i]; o.ab_static[i] = (T)p.ab_static[i]; o.wb_static[i] = (T)p.wb_static[i]; }
+    for (int i = 0; i < 4; ++i) o.q_vc[i] = (T)d.q_vc[i];
+    for (int i = 0; i < 9; ++i) o.C_vc[i] = (T)d.C_vc[i];
+    for (int i = 0; i < 12; ++i) o.Q[i] = (T)d.Q[i];
+    for (int i = 0; i < 6; ++i) o.R[i] = (T)d.R[i];
+    return o;
+}
+template <typename T> static const DevParams<T>& dev(const qle_batch* h);
+template <> const DevParams<float>& dev<float>(const qle_batch* h) { return h->pf; }
+template <> const DevParams<double>& dev<double>(const qle_batch* h) { return h->pd; }
+
+static inline dim3 grid_for(const qle_batch* h, int block) { return dim3((unsigned)((h->B + block - 1) / block)); }
+
+static int check_handle(const qle_batch* h)
+{
+    if (!h) return fail(QLE_ERR_INVALID, "handle is null");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(QLE_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
+    return QLE_OK;
+}
+
+extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
+{
+    QLE_TRY(check_handle(h));
+    if (!p) return fail(QLE_ERR_INVALID, "params is null");
+    qle_derived d;
+    QLE_TRY(qle_params_derive(p, &d));
+    h->pub = *p;
+    h->der = d;
+    h->pf = make_dev<float>(*p, d);
+    h->pd = make_dev<double>(*p, d);
+    return QLE_OK;
+}
+
+extern "C" int qle_destroy(qle_batch* h)
+{
+    if (!h) return QLE_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    void* bufs[] = {h->x, h->P, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return QLE_OK;
+}
+
+extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t device, const qle_params* p)
+{
+    if (!out) return fail(QLE_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (batch <= 0) return fail(QLE_ERR_INVALID, "batch must be > 0 (got %lld)", (long long)batch);
+    if (dtype != QLE_F32 && dtype != QLE_F64) return fail(QLE_ERR_INVALID, "dtype must be QLE_F32 or QLE_F64");
+    if (!p) return fail(QLE_ERR_INVALID, "params is null");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(QLE_ERR_NO_DEVICE, "no HIP device available (%s); this engine has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(QLE_ERR_NO_DEVICE, "device %d out of range (have %d)", device, ndev);
+    qle_batch* h = new (std::nothrow) qle_batch();
+    if (!h) return fail(QLE_ERR_NOMEM, "host allocation failed");
+    h->B = batch;
+    h->dtype = dtype;
+    h->device = device;
+    h->wsz = dtype == QLE_F32 ? 4 : 8;
+    if (const char* s = std::getenv("QLE_BLOCK")) {
+        int b = std::atoi(s);
+        if (b == 64 || b == 128 || b == 256) h->block = b;
+    }
+    int rc = QLE_OK;
+    auto bail = [&](int code) { qle_destroy(h); return code; };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipSetDevice(%d) failed", device));
+    if ((rc = qle_set_params(h, p)) != QLE_OK) return bail(rc);
+#define ALLOC(ptr, bytes)                                                                               \
+    do {                                                                                                \
+        hipError_t ea_ = hipMalloc((void**)&(ptr), (bytes));                                            \
+        if (ea_ != hipSuccess) return bail(fail(QLE_ERR_NOMEM, "hipMalloc(%zu B) for %s: %s", (size_t)(bytes), #ptr, hipGetErrorString(ea_))); \
+    } while (0)
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipStreamCreate failed"));
+    if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipEventCreate failed"));
+    const size_t B = (size_t)batch, w = h->wsz;
+    ALLOC(h->x, kXW * B * w);
+    ALLOC(h->P, kPW * B * w);
+    ALLOC(h->tick_u, kUW * B * w + 256);
+    ALLOC(h->tick_z, kZW * B * w);
+    ALLOC(h->stage, (size_t)kStageDoubles * sizeof(double));
+    ALLOC(h->stage_mask, (size_t)kStageFilters);
+    ALLOC(h->counter, sizeof(unsigned long long));
+#undef ALLOC
+    if (hipMemsetAsync(h->x, 0, kXW * B * w, h->stream) != hipSuccess || hipMemsetAsync(h->P, 0, kPW * B * w, h->stream) != hipSuccess)
+        return bail(fail(QLE_ERR_HIP, "hipMemsetAsync failed"));
+    *out = h;
+    return QLE_OK;
+}
+
+extern "C" int64_t qle_batch_size(const qle_batch* h) { return h ? h->B : 0; }
+extern "C" int32_t qle_dtype(const qle_batch* h) { return h ? h->dtype : -1; }
+extern "C" int32_t qle_num_states(const qle_batch* h) { return h ? h->der.num_states : 0; }
+
+extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
+{   // packed P, SoA, one streamed tick
+    if (!h) return 0;
+    int64_t words = kind == 0 ? (16 + 120 + 6) + (16 + 120) : kind == 1 ? (16 + 120 + 6 + 7) + (16 + 120) : (16 + 120 + 7) + (16 + 120);
+    if (h->pfp_on) words += kFW;
+    return words * (int64_t)h->wsz * h->B;
+}
+
+extern "C" int qle_synchronize(qle_batch* h)
+{
+    QLE_TRY(check_handle(h));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return QLE_OK;
+}
+extern "C" int qle_timer_begin(qle_batch* h)
+{
+    QLE_TRY(check_handle(h));
+    HIP_TRY(hipEventRecord(h->ev0, h->stream));
+    return QLE_OK;
+}
+extern "C" int qle_timer_end(qle_batch* h, float* ms)
+{
+    QLE_TRY(check_handle(h));
+    if (!ms) return fail(QLE_ERR_INVALID, "elapsed_ms is null");
+    HIP_TRY(hipEventRecord(h->ev1, h->stream));
+    HIP_TRY(hipEventSynchronize(h->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, h->ev0, h->ev1));
+    return QLE_OK;
+}
+
+// --------------------------------------------------- staging (not hot path)
+// Chunked AoS fp64 host -> device quad rows.  `W` words per filter taken from
+// a host row of `stride` doubles; dst rows have pitch B and start at filter 0.
+template <typename T>
+static int pack_rows(qle_batch* h, const double* host, int stride, int W, void* dst)
+{
+    const int64_t chunk = std::min<int64_t>(kStageFilters, kStageDoubles / std::max(stride, 1));
+    for (int64_t i0 = 0; i0 < h->B; i0 += chunk) {
+        const int64_t n = std::min(chunk, h->B - i0);
+        HIP_TRY(hipMemcpyAsync(h->stage, host + i0 * stride, (size_t)n * stride * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        // dst + i0 words: word_off is linear in i for a fixed row, so shifting the base by i0*VW
+        // words addresses filters [i0, i0+n) of every row while keeping pitch B.
+        hipLaunchKernelGGL((k_pack_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->stage, stride, W,
+                           (T*)dst, h->B, i0, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));  // staging buffer is reused by the next chunk
+    }
+    return QLE_OK;
+}
+template <typename T>
+static int unpack_rows(qle_batch* h, const void* src, int stride, int W, double* host)
+{
+    const int64_t chunk = std::min<int64_t>(kStageFilters, kStageDoubles / std::max(stride, 1));
+    for (int64_t i0 = 0; i0 < h->B; i0 += chunk) {
+        const int64_t n = std::min(chunk, h->B - i0);
+        hipLaunchKernelGGL((k_unpack_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, stride, W, h->stage,
+                           h->B, i0, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host + i0 * stride, h->stage, (size_t)n * stride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return QLE_OK;
+}
+template <typename T>
+static int pack_z(qle_batch* h, const double* z, const uint8_t* mask, void* dst)
+{
+    for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
+        const int64_t n = std::min(kStageFilters, h->B - i0);
+        if (z) HIP_TRY(hipMemcpyAsync(h->stage, z + i0 * 7, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (mask) HIP_TRY(hipMemcpyAsync(h->stage_mask, mask + i0, (size_t)n, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL((k_pack_z_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, z ? (const double*)h->stage : nullptr,
+                           mask ? (const uint8_t*)h->stage_mask : nullptr, (T*)dst, h->B, i0, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return QLE_OK;
+}
+template <typename T>
+static int pack_P(qle_batch* h, const double* P, void* dst)
+{
+    const int n = h->der.num_states;
+    for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
+        const int64_t m = std::min(kStageFilters, h->B - i0);
+        HIP_TRY(hipMemcpyAsync(h->stage, P + i0 * n * n, (size_t)m * n * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL((k_pack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->stage, n, (T*)dst,
+                           h->B, i0, m);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return QLE_OK;
+}
+template <typename T>
+static int unpack_P(qle_batch* h, const void* src, double* P)
+{
+    const int n = h->der.num_states;
+    for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
+        const int64_t m = std::min(kStageFilters, h->B - i0);
+        hipLaunchKernelGGL((k_unpack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, n, h->stage, h->B, i0,
+                           m);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(P + i0 * n * n, h->stage, (size_t)m * n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return QLE_OK;
+}
+
+#define BY_DTYPE(h, FN, ...) ((h)->dtype == QLE_F32 ? FN<float>(__VA_ARGS__) : FN<double>(__VA_ARGS__))
+
+extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
+{
+    QLE_TRY(check_handle(h));
+    if (!x || !P) return fail(QLE_ERR_INVALID, "x and P must be non-null");
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, h->x));
+    QLE_TRY(BY_DTYPE(h, pack_P, h, P, h->P));
+    h->state_set = true;
+    return QLE_OK;
+}
+extern "C" int qle_get_state(qle_batch* h, double* x, double* P)
+{
+    QLE_TRY(check_handle(h));
+    if (x) QLE_TRY(BY_DTYPE(h, unpack_rows, h, h->x, kXW, kXW, x));
+    if (P) QLE_TRY(BY_DTYPE(h, unpack_P, h, h->P, P));
+    return QLE_OK;
+}
+
+extern "C" int qle_set_filter_params(qle_batch* h, const double* pfp)
+{
+    QLE_TRY(check_handle(h));
+    if (!pfp) { h->pfp_on = false; return QLE_OK; }
+    if (!h->pfp) HIP_TRY(hipMalloc(&h->pfp, kFW * (size_t)h->B * h->wsz));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, pfp, kFW, kFW, h->pfp));
+    h->pfp_on = true;
+    return QLE_OK;
+}
+
+extern "C" int qle_enable_aux(qle_batch* h, int32_t on)
+{
+    QLE_TRY(check_handle(h));
+    if (on && !h->aux_accel) {
+        HIP_TRY(hipMalloc(&h->aux_accel, 3 * (size_t)h->B * h->wsz));
+        HIP_TRY(hipMalloc(&h->aux_obs, 7 * (size_t)h->B * h->wsz));
+        HIP_TRY(hipMemsetAsync(h->aux_accel, 0, 3 * (size_t)h->B * h->wsz, h->stream));
+        HIP_TRY(hipMemsetAsync(h->aux_obs, 0, 7 * (size_t)h->B * h->wsz, h->stream));
+    }
+    h->aux = on != 0;
+    return QLE_OK;
+}
+template <typename T>
+static int get_aux_t(qle_batch* h, double* accel, double* obs)
+{
+    std::vector<T> tmp((size_t)h->B * 7);
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (accel) {
+        HIP_TRY(hipMemcpy(tmp.data(), h->aux_accel, (size_t)h->B * 3 * sizeof(T), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < h->B * 3; ++k) accel[k] = (double)tmp[k];
+    }
+    if (obs) {
+        HIP_TRY(hipMemcpy(tmp.data(), h->aux_obs, (size_t)h->B * 7 * sizeof(T), hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < h->B * 7; ++k) obs[k] = (double)tmp[k];
+    }
+    return QLE_OK;
+}
+extern "C" int qle_get_aux(qle_batch* h, double* accel_rel, double* obs)
+{
+    QLE_TRY(check_handle(h));
+    if (!h->aux_accel) return fail(QLE_ERR_STATE, "aux outputs are not enabled (qle_enable_aux)");
+    return BY_DTYPE(h, get_aux_t, h, accel_rel, obs);
+}
+
+// -------------------------------------------------------------- hot launches
+template <typename T>
+static int launch_predict(qle_batch* h, const void* u)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T *x = (T*)h->x, *P = (T*)h->P, *acc = (T*)h->aux_accel;
+    const T* pfp = (const T*)h->pfp;
+    if (h->pfp_on) {
+        if (h->aux) hipLaunchKernelGGL((k_predict<T, true, true>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
+        else hipLaunchKernelGGL((k_predict<T, true, false>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
+    } else {
+        if (h->aux) hipLaunchKernelGGL((k_predict<T, false, true>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
+        else hipLaunchKernelGGL((k_predict<T, false, false>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
+    }
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+
+template <typename T, bool DIRECT>
+static int launch_step_d(qle_batch* h, const void* u, const void* z)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T *x = (T*)h->x, *P = (T*)h->P, *acc = (T*)h->aux_accel, *obs = (T*)h->aux_obs;
+    const T* pfp = (const T*)h->pfp;
+    if (h->pfp_on) {
+        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, true, true>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+        else hipLaunchKernelGGL((k_step<T, DIRECT, true, false>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+    } else {
+        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, false, true>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+        else hipLaunchKernelGGL((k_step<T, DIRECT, false, false>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+    }
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+template <typename T>
+static int launch_step(qle_batch* h, const void* u, const void* z)
+{
+    return h->pub.direct_orien_method ? launch_step_d<T, true>(h, u, z) : launch_step_d<T, false>(h, u, z);
+}
+
+template <typename T, bool DIRECT>
+static int launch_update_d(qle_batch* h, const void* z)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T *x = (T*)h->x, *P = (T*)h->P, *obs = (T*)h->aux_obs;
+    const T* pfp = (const T*)h->pfp;
+    if (h->pfp_on) {
+        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, true, true>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
+        else hipLaunchKernelGGL((k_update<T, DIRECT, true, false>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
+    } else {
+        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, false, true>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
+        else hipLaunchKernelGGL((k_update<T, DIRECT, false, false>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
+    }
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+template <typename T>
+static int launch_update(qle_batch* h, const void* z)
+{
+    return h->pub.direct_orien_method ? launch_update_d<T, true>(h, z) : launch_update_d<T, false>(h, z);
+}
+
+static int need_state(const qle_batch* h)
+{
+    if (!h->state_set) return fail(QLE_ERR_STATE, "state not initialised: call qle_set_state or qle_initialize_state first (EKF.cpp:129-130)");
+    return QLE_OK;
+}
+
+extern "C" int qle_predict(qle_batch* h, const double* u)
+{
+    QLE_TRY(check_handle(h));
+    QLE_TRY(need_state(h));
+    if (!u) return fail(QLE_ERR_INVALID, "u is null");
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u));
+    return BY_DTYPE(h, launch_predict, h, h->tick_u);
+}
+extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)
+{
+    QLE_TRY(check_handle(h));
+    QLE_TRY(need_state(h));
+    if (!z) return fail(QLE_ERR_INVALID, "z is null");
+    QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
+    return BY_DTYPE(h, launch_update, h, h->tick_z);
+}
+extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const uint8_t* mask)
+{
+    QLE_TRY(check_handle(h));
+    QLE_TRY(need_state(h));
+    if (!u) return fail(QLE_ERR_INVALID, "u is null");
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u));
+    if (!z) return BY_DTYPE(h, launch_predict, h, h->tick_u);
+    QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
+    return BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z);
+}
+
+template <typename T>
+static int seed_t(qle_batch* h, int reinit)
+{
+    const qle_derived& d = h->der;
+    hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)h->x, (T*)h->P,
+                       (T)d.cov_init[0], (T)d.cov_init[3], (T)d.cov_init[6], (T)d.cov_init[9], (T)d.cov_init[12], reinit, h->B);
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+extern "C" int qle_initialize_state(qle_batch* h, const double* z, int32_t reinit_bias)
+{
+    QLE_TRY(check_handle(h));
+    if (!z) return fail(QLE_ERR_INVALID, "z is null");
+    QLE_TRY(BY_DTYPE(h, pack_z, h, z, (const uint8_t*)nullptr, h->tick_z));
+    QLE_TRY(BY_DTYPE(h, seed_t, h, reinit_bias));
+    h->state_set = true;
+    return QLE_OK;
+}
+
+// ---------------------------------------------------------------- reporting
+template <typename T>
+static int report_t(qle_batch* h, double* pose, double* cov, double* vel, double* bias)
+{
+    // staged per chunk: 7 + 36 + 3 + 6 = 52 doubles per filter
+    for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
+        const int64_t n = std::min(kStageFilters, h->B - i0);
+        double* s_pose = h->stage;
+        double* s_cov = s_pose + n * 7;
+        double* s_vel = s_cov + n * 36;
+        double* s_bias = s_vel + n * 3;
+        hipLaunchKernelGGL((k_report_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->x, (const T*)h->P,
+                           h->pfp_on ? (const T*)h->pfp : (const T*)nullptr, s_pose, s_cov, s_vel, s_bias, h->B, i0, n);
+        HIP_TRY(hipGetLastError());
+        if (pose) HIP_TRY(hipMemcpyAsync(pose + i0 * 7, s_pose, (size_t)n * 7 * 8, hipMemcpyDeviceToHost, h->stream));
+        if (cov) HIP_TRY(hipMemcpyAsync(cov + i0 * 36, s_cov, (size_t)n * 36 * 8, hipMemcpyDeviceToHost, h->stream));
+        if (vel) HIP_TRY(hipMemcpyAsync(vel + i0 * 3, s_vel, (size_t)n * 3 * 8, hipMemcpyDeviceToHost, h->stream));
+        if (bias) HIP_TRY(hipMemcpyAsync(bias + i0 * 6, s_bias, (size_t)n * 6 * 8, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return QLE_OK;
+}
+extern "C" int qle_get_report(qle_batch* h, double* pose, double* pose_cov, double* vel, double* bias)
+{
+    QLE_TRY(check_handle(h));
+    return BY_DTYPE(h, report_t, h, pose, pose_cov, vel, bias);
+}
+
+template <typename T>
+static int nonfinite_t(qle_batch* h)
+{
+    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->x, (const T*)h->P, h->counter, h->B);
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+extern "C" int qle_count_nonfinite(qle_batch* h, int64_t* count)
+{
+    QLE_TRY(check_handle(h));
+    if (!count) return fail(QLE_ERR_INVALID, "count is null");
+    HIP_TRY(hipMemsetAsync(h->counter, 0, sizeof(unsigned long long), h->stream));
+    QLE_TRY(BY_DTYPE(h, nonfinite_t, h));
+    unsigned long long c = 0;
+    HIP_TRY(hipMemcpyAsync(&c, h->counter, sizeof(c), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    *count = (int64_t)c;
+    return QLE_OK;
+}
+
+// ------------------------------------------------- device-resident sequences
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+extern "C" int qle_inputs_destroy(qle_inputs* in)
+{
+    if (!in) return QLE_OK;
+    if (in->h) (void)hipSetDevice(in->h->device);
+    void* bufs[] = {in->u, in->z, in->truth, in->truth_bias};
+    for (void* b : bufs)
+        if (b) (void)hipFree(b);
+    delete in;
+    return QLE_OK;
+}
+
+extern "C" int qle_inputs_create(qle_batch* h, int64_t n_ticks, const uint8_t* tick_has_meas, qle_inputs** out)
+{
+    QLE_TRY(check_handle(h));
+    if (!out) return fail(QLE_ERR_INVALID, "out is null");
+    *out = nullptr;
+    if (n_ticks <= 0) return fail(QLE_ERR_INVALID, "n_ticks must be > 0");
+    qle_inputs* in = new (std::nothrow) qle_inputs();
+    if (!in) return fail(QLE_ERR_NOMEM, "host allocation failed");
+    in->h = h;
+    in->T = n_ticks;
+    in->slot.assign((size_t)n_ticks, -1);
+    for (int64_t t = 0; t < n_ticks; ++t)
+        if (tick_has_meas && tick_has_meas[t]) in->slot[(size_t)t] = (int32_t)in->n_slots++;
+    in->pitch_u = align_up(kUW * (size_t)h->B * h->wsz, 256);
+    in->pitch_z = align_up(kZW * (size_t)h->B * h->wsz, 256);
+    hipError_t e = hipMalloc(&in->u, in->pitch_u * (size_t)n_ticks);
+    if (e == hipSuccess && in->n_slots) e = hipMalloc(&in->z, in->pitch_z * (size_t)in->n_slots);
+    if (e == hipSuccess) e = hipMalloc(&in->truth, (size_t)h->B * 7 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc(&in->truth_bias, (size_t)h->B * 6 * sizeof(double));
+    if (e != hipSuccess) {
+        qle_inputs_destroy(in);
+        return fail(QLE_ERR_NOMEM, "hipMalloc for %lld ticks of inputs: %s", (long long)n_ticks, hipGetErrorString(e));
+    }
+    *out = in;
+    return QLE_OK;
+}
+
+static int check_tick(const qle_inputs* in, int64_t t)
+{
+    if (!in) return fail(QLE_ERR_INVALID, "inputs is null");
+    if (t < 0 || t >= in->T) return fail(QLE_ERR_INVALID, "tick %lld out of range [0,%lld)", (long long)t, (long long)in->T);
+    return QLE_OK;
+}
+static inline void* u_at(const qle_inputs* in, int64_t t) { return (char*)in->u + in->pitch_u * (size_t)t; }
+static inline void* z_at(const qle_inputs* in, int32_t s) { return (char*)in->z + in->pitch_z * (size_t)s; }
+
+extern "C" int qle_inputs_upload_tick(qle_inputs* in, int64_t t, const double* u, const double* z, const uint8_t* mask)
+{
+    QLE_TRY(check_tick(in, t));
+    qle_batch* h = in->h;
+    QLE_TRY(check_handle(h));
+    if (!u) return fail(QLE_ERR_INVALID, "u is null");
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, u_at(in, t)));
+    const int32_t s = in->slot[(size_t)t];
+    if (s >= 0) {
+        if (!z) return fail(QLE_ERR_INVALID, "tick %lld has a measurement slot but z is null", (long long)t);
+        QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, z_at(in, s)));
+    } else if (z) {
+        return fail(QLE_ERR_INVALID, "tick %lld has no measurement slot", (long long)t);
+    }
+    return QLE_OK;
+}
+
+template <typename T>
+static int unpack_z(qle_batch* h, const void* src, double* z, uint8_t* mask)
+{
+    for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
+        const int64_t n = std::min(kStageFilters, h->B - i0);
+        hipLaunchKernelGGL((k_unpack_z_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, h->stage, h->stage_mask,
+                           h->B, i0, n);
+        HIP_TRY(hipGetLastError());
+        if (z) HIP_TRY(hipMemcpyAsync(z + i0 * 7, h->stage, (size_t)n * 7 * 8, hipMemcpyDeviceToHost, h->stream));
+        if (mask) HIP_TRY(hipMemcpyAsync(mask + i0, h->stage_mask, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+    }
+    return QLE_OK;
+}
+extern "C" int qle_inputs_download_tick(qle_inputs* in, int64_t t, double* u, double* z, uint8_t* mask)
+{
+    QLE_TRY(check_tick(in, t));
+    qle_batch* h = in->h;
+    QLE_TRY(check_handle(h));
+    if (u) QLE_TRY(BY_DTYPE(h, unpack_rows, h, u_at(in, t), kUW, kUW, u));
+    const int32_t s = in->slot[(size_t)t];
+    if (s >= 0 && (z || mask)) QLE_TRY(BY_DTYPE(h, unpack_z, h, z_at(in, s), z, mask));
+    if (s < 0 && mask) std::memset(mask, 0, (size_t)h->B);
+    return QLE_OK;
+}
+
+extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
+{
+    QLE_TRY(check_handle(h));
+    QLE_TRY(need_state(h));
+    if (!in || in->h != h) return fail(QLE_ERR_INVALID, "inputs do not belong to this handle");
+    if (t0 < 0 || n < 0) return fail(QLE_ERR_INVALID, "t0 and n must be >= 0");
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t t = (t0 + k) % in->T;
+        const int32_t s = in->slot[(size_t)t];
+        if (s < 0) QLE_TRY(BY_DTYPE(h, launch_predict, h, u_at(in, t)));
+        else QLE_TRY(BY_DTYPE(h, launch_step, h, u_at(in, t), z_at(in, s)));
+    }
+    return QLE_OK;
+}
+
+// ------------------------------------------------------ synthetic generator
+extern "C" int qle_synth_cfg_default(qle_synth_cfg* c)
+{
+    if (!c) return fail(QLE_ERR_INVALID, "cfg is null");
+    std::memset(c, 0, sizeof(*c));
+    c->seed = 0xE4F00003ULL;
+    c->ab_true_sigma = 0.1;
+    c->wb_true_sigma = 0.01;
+    c->meas_noise_scale = 1.0;
+    c->imu_noise_scale = 1.0;
+    return QLE_OK;
+}
+
+template <typename T>
+static int synth_t(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
+{
+    SynthArgs a;
+    a.seed = c->seed;
+    a.filter_offset = c->filter_offset;
+    a.ab_sigma = c->ab_true_sigma;
+    a.wb_sigma = c->wb_true_sigma;
+    a.meas_scale = c->meas_noise_scale;
+    a.imu_scale = c->imu_noise_scale;
+    a.perturb = c->perturb_filter_params;
+    a.dT = h->der.dT_nom;
+    for (int i = 0; i < 12; ++i) a.Q[i] = h->der.Q[i];
+    for (int i = 0; i < 6; ++i) a.R[i] = h->der.R[i];
+    for (int i = 0; i < 3; ++i) { a.g[i] = h->pub.g[i]; a.r_v_cv[i] = h->pub.r_v_cv[i]; a.ab_static[i] = h->pub.ab_static[i]; a.wb_static[i] = h->pub.wb_static[i]; }
+    for (int i = 0; i < 4; ++i) a.q_vc[i] = h->der.q_vc[i];
+    for (int i = 0; i < 9; ++i) a.C_vc[i] = h->der.C_vc[i];
+    a.est_bias = h->pub.est_bias;
+    a.T = in->T;
+    a.B = h->B;
+    a.pitch_u_words = (int64_t)(in->pitch_u / h->wsz);
+    a.pitch_z_words = (int64_t)(in->pitch_z / h->wsz);
+    // slot table on device
+    int32_t* d_slot = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_slot, sizeof(int32_t) * (size_t)in->T));
+    hipError_t e = hipMemcpyAsync(d_slot, in->slot.data(), sizeof(int32_t) * (size_t)in->T, hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess) {
+        if (c->perturb_filter_params && !h->pfp) e = hipMalloc(&h->pfp, kFW * (size_t)h->B * h->wsz);
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL((k_synth<T>), grid_for(h, 64), dim3(64), 0, h->stream, a, (const int32_t*)d_slot, (T*)in->u, (T*)in->z, (T*)h->tick_z,
+                           c->perturb_filter_params ? (T*)h->pfp : (T*)nullptr, (double*)in->truth, (double*)in->truth_bias);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    (void)hipFree(d_slot);
+    if (e != hipSuccess) return fail(QLE_ERR_HIP, "synthetic generator: %s", hipGetErrorString(e));
+    if (c->perturb_filter_params) h->pfp_on = true;
+    in->has_truth = true;
+    return QLE_OK;
+}
+
+extern "C" int qle_synth_generate(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
+{
+    QLE_TRY(check_handle(h));
+    if (!in || in->h != h) return fail(QLE_ERR_INVALID, "inputs do not belong to this handle");
+    if (!c) return fail(QLE_ERR_INVALID, "cfg is null");
+    QLE_TRY(BY_DTYPE(h, synth_t, h, in, c));
+    // seed every filter from the generator's first (pre-sequence) tag pose, left in tick_z
+    QLE_TRY(BY_DTYPE(h, seed_t, h, 1));
+    h->state_set = true;
+    return QLE_OK;
+}
+
+template <typename T>
+static int rmse_t(qle_batch* h, const qle_inputs* in, double* d_out)
+{
+    hipLaunchKernelGGL((k_rmse<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->x, (const double*)in->truth, d_out, h->B);
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+extern "C" int qle_synth_rmse(qle_batch* h, const qle_inputs* in, double out[3])
+{
+    QLE_TRY(check_handle(h));
+    if (!in || in->h != h || !out) return fail(QLE_ERR_INVALID, "bad arguments");
+    if (!in->has_truth) return fail(QLE_ERR_STATE, "inputs hold no generated truth (qle_synth_generate)");
+    double* d_out = h->stage;  // 3 doubles of the staging buffer
+    HIP_TRY(hipMemsetAsync(d_out, 0, 3 * sizeof(double), h->stream));
+    QLE_TRY(BY_DTYPE(h, rmse_t, h, in, d_out));
+    HIP_TRY(hipMemcpyAsync(out, d_out, 3 * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return QLE_OK;
+}

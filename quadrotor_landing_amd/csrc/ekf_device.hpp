@@ -1,0 +1,496 @@
+// ekf_device.hpp -- per-filter arithmetic of the batched relative-pose EKF,
+// written for one filter per lane with the whole 15x15 covariance (packed
+// symmetric, 120 words) held in VGPRs.  gfx950 (CDNA4) only.
+//
+// Reference behaviour being reproduced (mbrymer/quadrotor_landing,
+// quad_state_estimation/):
+//   src/relative_pose_EKF.cpp:346-415  prediction_step
+//   src/relative_pose_EKF.cpp:417-502  correction_step
+//   src/quaternion_helper.cpp:9-100    quaternion_exp / log / norm, skew_symm
+// The reference forms dense 15x15 F and W and multiplies them out.  Here the
+// block structure of F is used directly: F = L3 * L2 * L1 with
+//   L1: r <- r + dT v                       (F[r,v]      EKF.cpp:380)
+//   L2: v <- v + A th + Bm ab               (F[v,th], F[v,ab]  EKF.cpp:381,399)
+//   L3: th <- Rt th - dT wb                 (F[th,th], F[th,wb] EKF.cpp:383-395,400)
+// and P <- L3 (L2 (L1 P L1^T) L2^T) L3^T + W Q W^T is applied as three in-place
+// symmetric congruences on the packed upper triangle (~620 FMA instead of
+// ~7000).  The correction uses the LDL^T (square-root-free Cholesky) form of
+// K = P G^T S^-1 and P <- P - (P G^T) S^-1 (P G^T)^T, one measurement
+// component at a time -- algebraically identical to EKF.cpp:475-481, different
+// rounding.  Every array index below is a compile-time constant after
+// unrolling, so nothing lives in scratch memory.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+namespace qle {
+
+// ------------------------------------------------------------------ scalars
+__device__ __forceinline__ float t_sqrt(float v) { return sqrtf(v); }
+__device__ __forceinline__ double t_sqrt(double v) { return sqrt(v); }
+__device__ __forceinline__ float t_atan2(float a, float b) { return atan2f(a, b); }
+__device__ __forceinline__ double t_atan2(double a, double b) { return atan2(a, b); }
+__device__ __forceinline__ void t_sincos(float v, float* s, float* c) { sincosf(v, s, c); }
+__device__ __forceinline__ void t_sincos(double v, double* s, double* c) { sincos(v, s, c); }
+
+// Packed upper-triangular index of the symmetric 15x15 covariance, row-major.
+__host__ __device__ constexpr int sidx(int i, int j)
+{
+    return (i <= j) ? (i * 15 - (i * (i - 1)) / 2 + (j - i)) : (j * 15 - (j * (j - 1)) / 2 + (i - j));
+}
+#define QLE_PS(i, j) P[::qle::sidx((i), (j))]
+
+// Uniform (per-launch) parameters in the compute dtype; derived on the host by
+// qle_params_derive == initialize_params (EKF.cpp:87-125).
+template <typename T>
+struct DevParams {
+    T dT;            // dT_nom (EKF.cpp:90,356)
+    T dTw;           // est_bias ? dT : 0   (F[th,wb] = -dT I only with est_bias, EKF.cpp:400)
+    T bias_on;       // est_bias ? 1 : 0    (F[v,ab] EKF.cpp:399; bias injection EKF.cpp:494-498)
+    T small_ang_tol; // EKF.cpp:80
+    T g[3];          // EKF.cpp:81
+    T q_vc[4];       // x,y,z,w, normalised (EKF.cpp:121)
+    T C_vc[9];       // EKF.cpp:122
+    T r_v_cv[3];     // EKF.cpp:55
+    T Q[12];         // diag(Q_a,Q_w,Q_ab,Q_wb) (EKF.cpp:100-112); zero where !est_bias
+    T R[6];          // diag(R_r,R_ang) (EKF.cpp:116-118)
+    T ab_static[3];  // EKF.cpp:357
+    T wb_static[3];  // EKF.cpp:358
+};
+
+// Noise / static-bias values a tick actually uses: shared or per filter (cfg 5).
+template <typename T>
+struct Noise {
+    T Q[12];
+    T ab_static[3];
+    T wb_static[3];
+    T R[6];
+};
+
+// ------------------------------------------------------ quaternion helpers
+// quaternion_norm, QH.cpp:61-73: normalise, then flip to the w >= -0.75 cover.
+template <typename T>
+__device__ __forceinline__ void quat_norm(T (&q)[4])
+{
+    T n = t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    T inv = T(1) / n;
+    T s = (q[3] * inv < T(-0.75)) ? -inv : inv;
+    q[0] *= s; q[1] *= s; q[2] *= s; q[3] *= s;
+}
+
+// quaternion_exp, QH.cpp:9-33 (including the final quaternion_norm at :30).
+template <typename T>
+__device__ __forceinline__ void quat_exp(const T (&v)[3], T (&q)[4])
+{
+    T n = t_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+    T sh, ch;
+    t_sincos(n * T(0.5), &sh, &ch);
+    bool small = n < T(1E-10);
+    T k = small ? T(0.5) * (T(1) - n * n * (T(1) / T(24))) : sh / (small ? T(1) : n);
+    q[0] = v[0] * k; q[1] = v[1] * k; q[2] = v[2] * k; q[3] = ch;
+    quat_norm(q);
+}
+
+// quaternion_log, QH.cpp:36-58.
+template <typename T>
+__device__ __forceinline__ void quat_log(const T (&q)[4], T (&v)[3])
+{
+    T m = t_sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2]);
+    bool small = m < T(1E-10);
+    T mw = m / q[3];
+    T k_small = T(2) / q[3] * (T(1) - mw * mw * (T(1) / T(3)));
+    T k_full = T(2) * t_atan2(m, q[3]) / (small ? T(1) : m);
+    T k = small ? k_small : k_full;
+    v[0] = k * q[0]; v[1] = k * q[1]; v[2] = k * q[2];
+}
+
+// Hamilton product, storage x,y,z,w (Eigen operator*, EKF.cpp:367,431,448,488).
+template <typename T>
+__device__ __forceinline__ void quat_mul(const T (&a)[4], const T (&b)[4], T (&o)[4])
+{
+    o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+    o[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+    o[1] = a[3] * b[1] + a[1] * b[3] + a[2] * b[0] - a[0] * b[2];
+    o[2] = a[3] * b[2] + a[2] * b[3] + a[0] * b[1] - a[1] * b[0];
+}
+
+// Rotation matrix of a unit quaternion (Eigen toRotationMatrix, EKF.cpp:359,429).
+template <typename T>
+__device__ __forceinline__ void quat_to_rot(const T (&q)[4], T (&C)[9])
+{
+    T x = q[0], y = q[1], z = q[2], w = q[3];
+    T tx = x + x, ty = y + y, tz = z + z;
+    T twx = tx * w, twy = ty * w, twz = tz * w;
+    T txx = tx * x, txy = ty * x, txz = tz * x;
+    T tyy = ty * y, tyz = tz * y, tzz = tz * z;
+    C[0] = T(1) - (tyy + tzz); C[1] = txy - twz;           C[2] = txz + twy;
+    C[3] = txy + twz;           C[4] = T(1) - (txx + tzz); C[5] = tyz - twx;
+    C[6] = txz - twy;           C[7] = tyz + twx;           C[8] = T(1) - (txx + tyy);
+}
+
+// ------------------------------------------------------------------ predict
+// prediction_step, EKF.cpp:346-415.  x and P are updated in place; accel is
+// pose_accel (EKF.cpp:362).
+template <typename T>
+__device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
+                                            const T (&u)[6], T (&accel)[3])
+{
+    const T dT = p.dT;
+    T a[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = u[i] - x[10 + i] - nz.ab_static[i];      // EKF.cpp:357
+        w[i] = u[3 + i] - x[13 + i] - nz.wb_static[i];  // EKF.cpp:358
+    }
+    T q[4] = {x[6], x[7], x[8], x[9]};
+    T C[9];
+    quat_to_rot(q, C);                                  // EKF.cpp:359
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        accel[i] = (C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]) + p.g[i];  // EKF.cpp:362
+
+    // nominal state, EKF.cpp:365-371
+    T dw[3] = {dT * w[0], dT * w[1], dT * w[2]};
+    T qe[4], qn[4];
+    quat_exp(dw, qe);
+    quat_mul(q, qe, qn);
+    quat_norm(qn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x[i] += dT * x[3 + i];
+        x[3 + i] += dT * accel[i];
+    }
+    x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+
+    // X = [A | Bm], A = -dT C [a]x (EKF.cpp:381), Bm = -dT C with est_bias (EKF.cpp:399)
+    T X[3][6];
+    const T mdT = -dT, mdTb = -dT * p.bias_on;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T c0 = C[3 * i], c1 = C[3 * i + 1], c2 = C[3 * i + 2];
+        X[i][0] = mdT * (c1 * a[2] - c2 * a[1]);
+        X[i][1] = mdT * (c2 * a[0] - c0 * a[2]);
+        X[i][2] = mdT * (c0 * a[1] - c1 * a[0]);
+        X[i][3] = mdTb * c0; X[i][4] = mdTb * c1; X[i][5] = mdTb * c2;
+    }
+    // Rt = F[th,th], EKF.cpp:383-395: I - [dw]x below small_ang_tol, else AngleAxis(-|dw|, dw/|dw|)
+    T Rt[3][3];
+    {
+        T ang = t_sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
+        bool small = ang < p.small_ang_tol;
+        T inv = T(1) / (small ? T(1) : ang);
+        T ax[3] = {dw[0] * inv, dw[1] * inv, dw[2] * inv};
+        T s, c;
+        t_sincos(-ang, &s, &c);
+        T sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
+        T ca[3] = {(T(1) - c) * ax[0], (T(1) - c) * ax[1], (T(1) - c) * ax[2]};
+        T t01 = ca[0] * ax[1], t02 = ca[0] * ax[2], t12 = ca[1] * ax[2];
+        Rt[0][0] = small ? T(1) : ca[0] * ax[0] + c;
+        Rt[1][1] = small ? T(1) : ca[1] * ax[1] + c;
+        Rt[2][2] = small ? T(1) : ca[2] * ax[2] + c;
+        Rt[0][1] = small ? dw[2] : t01 - sa[2];
+        Rt[1][0] = small ? -dw[2] : t01 + sa[2];
+        Rt[0][2] = small ? -dw[1] : t02 + sa[1];
+        Rt[2][0] = small ? dw[1] : t02 - sa[1];
+        Rt[1][2] = small ? dw[0] : t12 - sa[0];
+        Rt[2][1] = small ? -dw[0] : t12 + sa[0];
+    }
+
+    // ---- congruence 1: r <- r + dT v -------------------------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int c = 6; c < 15; ++c) QLE_PS(i, c) += dT * QLE_PS(3 + i, c);
+    }
+    {
+        T rv_old[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                rv_old[i][j] = QLE_PS(i, 3 + j);
+                QLE_PS(i, 3 + j) = rv_old[i][j] + dT * QLE_PS(3 + i, 3 + j);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = i; j < 3; ++j) QLE_PS(i, j) += dT * (rv_old[j][i] + QLE_PS(i, 3 + j));
+        }
+    }
+
+    // ---- congruence 2: v <- v + X [th; ab] -------------------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // P_rv += P_r,[th ab] X^T
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            T s = QLE_PS(i, 3 + j);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) s += X[j][m] * QLE_PS(i, 6 + m);
+            QLE_PS(i, 3 + j) = s;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {  // P_v,wb += X P_[th ab],wb
+#pragma unroll
+        for (int c = 12; c < 15; ++c) {
+            T s = QLE_PS(3 + i, c);
+#pragma unroll
+            for (int m = 0; m < 6; ++m) s += X[i][m] * QLE_PS(6 + m, c);
+            QLE_PS(3 + i, c) = s;
+        }
+    }
+    {
+        T vj_old[3][6], N[3][6];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) vj_old[i][c] = QLE_PS(3 + i, 6 + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                T s = vj_old[i][c];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) s += X[i][m] * QLE_PS(6 + m, 6 + c);
+                N[i][c] = s;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = i; k < 3; ++k) {
+                T s = QLE_PS(3 + i, 3 + k);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) s += X[i][m] * vj_old[k][m];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) s += N[i][m] * X[k][m];
+                QLE_PS(3 + i, 3 + k) = s;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) QLE_PS(3 + i, 6 + c) = N[i][c];
+        }
+    }
+
+    // ---- congruence 3: th <- Rt th - dTw wb ------------------------------
+    const T dTw = p.dTw;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {  // rows r,v: P_k,th <- P_k,th Rt^T - dTw P_k,wb
+        T o0 = QLE_PS(i, 6), o1 = QLE_PS(i, 7), o2 = QLE_PS(i, 8);
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            QLE_PS(i, 6 + j) = (Rt[j][0] * o0 + Rt[j][1] * o1 + Rt[j][2] * o2) - dTw * QLE_PS(i, 12 + j);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {  // P_th,ab <- Rt P_th,ab - dTw P_wb,ab
+        T o0 = QLE_PS(6, 9 + c), o1 = QLE_PS(7, 9 + c), o2 = QLE_PS(8, 9 + c);
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            QLE_PS(6 + i, 9 + c) = (Rt[i][0] * o0 + Rt[i][1] * o1 + Rt[i][2] * o2) - dTw * QLE_PS(9 + c, 12 + i);
+    }
+    {
+        T N[3][3], tw[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {  // N = Rt P_th,th - dTw P_wb,th   (old P_th,wb)
+#pragma unroll
+            for (int m = 0; m < 3; ++m)
+                N[i][m] = (Rt[i][0] * QLE_PS(6, 6 + m) + Rt[i][1] * QLE_PS(7, 6 + m) + Rt[i][2] * QLE_PS(8, 6 + m)) -
+                          dTw * QLE_PS(6 + m, 12 + i);
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {  // P_th,wb <- Rt P_th,wb - dTw P_wb,wb
+            T o0 = QLE_PS(6, 12 + c), o1 = QLE_PS(7, 12 + c), o2 = QLE_PS(8, 12 + c);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                tw[i][c] = (Rt[i][0] * o0 + Rt[i][1] * o1 + Rt[i][2] * o2) - dTw * QLE_PS(12 + i, 12 + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = i; k < 3; ++k)
+                QLE_PS(6 + i, 6 + k) = (N[i][0] * Rt[k][0] + N[i][1] * Rt[k][1] + N[i][2] * Rt[k][2]) - dTw * tw[i][k];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) QLE_PS(6 + i, 12 + c) = tw[i][c];
+        }
+    }
+
+    // ---- W Q W^T, EKF.cpp:402-414: blockdiag(0, C Qa C^T, Qw, Qab, Qwb) ----
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T cq0 = C[3 * i] * nz.Q[0], cq1 = C[3 * i + 1] * nz.Q[1], cq2 = C[3 * i + 2] * nz.Q[2];
+#pragma unroll
+        for (int k = i; k < 3; ++k) QLE_PS(3 + i, 3 + k) += cq0 * C[3 * k] + cq1 * C[3 * k + 1] + cq2 * C[3 * k + 2];
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        QLE_PS(6 + i, 6 + i) += nz.Q[3 + i];
+        QLE_PS(9 + i, 9 + i) += nz.Q[6 + i];
+        QLE_PS(12 + i, 12 + i) += nz.Q[9 + i];
+    }
+}
+
+// ------------------------------------------------------------------- update
+// correction_step, EKF.cpp:417-502.  z = [r_c_tc(3), q_ct(x,y,z,w)(4)].
+// obs receives r_t_vt_obs(3), q_tv_obs(4) (members written at EKF.cpp:431-443).
+template <typename T, bool DIRECT>
+__device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
+                                           const T (&z)[7], T (&obs)[7])
+{
+    T q[4] = {x[6], x[7], x[8], x[9]};
+    T r[3] = {x[0], x[1], x[2]};
+    T Cc[9];
+    quat_to_rot(q, Cc);                                      // EKF.cpp:429
+    T qo[4];
+    {
+        T qct[4] = {z[3], z[4], z[5], z[6]}, t[4];
+        quat_mul(p.q_vc, qct, t);                            // EKF.cpp:431
+        qo[0] = -t[0]; qo[1] = -t[1]; qo[2] = -t[2]; qo[3] = t[3];
+        quat_norm(qo);                                       // EKF.cpp:432
+    }
+    T dy[6];
+    {
+        // EKF.cpp:434-444: -(q * T_vc * r_c_tc) with q = q_tv_obs (direct) or q_check
+        T Cq[9];
+        if (DIRECT) quat_to_rot(qo, Cq);
+        else {
+#pragma unroll
+            for (int i = 0; i < 9; ++i) Cq[i] = Cc[i];
+        }
+        T pv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+            pv[i] = (p.C_vc[3 * i] * z[0] + p.C_vc[3 * i + 1] * z[1] + p.C_vc[3 * i + 2] * z[2]) + p.r_v_cv[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T ro = -(Cq[3 * i] * pv[0] + Cq[3 * i + 1] * pv[1] + Cq[3 * i + 2] * pv[2]);
+            obs[i] = ro;
+            dy[i] = ro - r[i];                               // EKF.cpp:447
+        }
+        obs[3] = qo[0]; obs[4] = qo[1]; obs[5] = qo[2]; obs[6] = qo[3];
+        T qc[4] = {-q[0], -q[1], -q[2], q[3]}, dq[4], dth[3];
+        quat_mul(qc, qo, dq);                                // EKF.cpp:448
+        quat_norm(dq);                                       // EKF.cpp:449
+        quat_log(dq, dth);                                   // EKF.cpp:450
+        dy[3] = dth[0]; dy[4] = dth[1]; dy[5] = dth[2];
+    }
+
+    // H = P G^T (15x6), G = [I 0 Gx 0 0; 0 0 I 0 0], Gx = Cc [Cc^T r]x unless direct (EKF.cpp:453-459)
+    T H[15][6];
+    T Gx[3][3];
+    if (!DIRECT) {
+        T b[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) b[i] = Cc[i] * r[0] + Cc[3 + i] * r[1] + Cc[6 + i] * r[2];  // Cc^T r
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            T c0 = Cc[3 * i], c1 = Cc[3 * i + 1], c2 = Cc[3 * i + 2];
+            Gx[i][0] = c1 * b[2] - c2 * b[1];
+            Gx[i][1] = c2 * b[0] - c0 * b[2];
+            Gx[i][2] = c0 * b[1] - c1 * b[0];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 15; ++k) {
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            H[k][3 + a] = QLE_PS(k, 6 + a);
+            T s = QLE_PS(k, a);
+            if (!DIRECT) s += Gx[a][0] * QLE_PS(k, 6) + Gx[a][1] * QLE_PS(k, 7) + Gx[a][2] * QLE_PS(k, 8);
+            H[k][a] = s;
+        }
+    }
+    // S = G H + R_k (upper triangle), R_k = N R N^T (EKF.cpp:462-472)
+    T S[6][6];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+#pragma unroll
+        for (int b = a; b < 6; ++b) {
+            T s = H[a][b];
+            if (!DIRECT) s += Gx[a][0] * H[6][b] + Gx[a][1] * H[7][b] + Gx[a][2] * H[8][b];
+            S[a][b] = s;
+        }
+#pragma unroll
+        for (int b = a; b < 3; ++b) S[3 + a][3 + b] = H[6 + a][3 + b];
+    }
+    {
+        T N00[3][3];  // -Cc C_vc
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                N00[i][j] = -(Cc[3 * i] * p.C_vc[j] + Cc[3 * i + 1] * p.C_vc[3 + j] + Cc[3 * i + 2] * p.C_vc[6 + j]);
+        }
+        // [r]x rows (EKF.cpp:465-468): row0 = (0,-r2,r1), row1 = (r2,0,-r0), row2 = (-r1,r0,0)
+        T Sr[3][3] = {{T(0), -r[2], r[1]}, {r[2], T(0), -r[0]}, {-r[1], r[0], T(0)}};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int j = i; j < 3; ++j) {
+                T s = N00[i][0] * nz.R[0] * N00[j][0] + N00[i][1] * nz.R[1] * N00[j][1] + N00[i][2] * nz.R[2] * N00[j][2];
+                if (DIRECT) s += Sr[i][0] * nz.R[3] * Sr[j][0] + Sr[i][1] * nz.R[4] * Sr[j][1] + Sr[i][2] * nz.R[5] * Sr[j][2];
+                S[i][j] += s;
+                S[3 + i][3 + j] += p.C_vc[3 * i] * nz.R[3] * p.C_vc[3 * j] + p.C_vc[3 * i + 1] * nz.R[4] * p.C_vc[3 * j + 1] +
+                                   p.C_vc[3 * i + 2] * nz.R[5] * p.C_vc[3 * j + 2];
+            }
+            if (DIRECT) {
+#pragma unroll
+                for (int j = 0; j < 3; ++j)
+                    S[i][3 + j] += Sr[i][0] * nz.R[3] * p.C_vc[3 * j] + Sr[i][1] * nz.R[4] * p.C_vc[3 * j + 1] +
+                                   Sr[i][2] * nz.R[5] * p.C_vc[3 * j + 2];
+            }
+        }
+    }
+
+    // LDL^T sweep over the 6 measurement components: after component c,
+    // P, H, S, dy hold the problem conditioned on components 0..c.
+    T dx[15];
+#pragma unroll
+    for (int k = 0; k < 15; ++k) dx[k] = T(0);
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        T invd = T(1) / S[c][c];
+        T yc = dy[c];
+        T h[15], s[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) { h[k] = H[k][c]; s[k] = h[k] * invd; }
+#pragma unroll
+        for (int i = 0; i < 15; ++i) {
+#pragma unroll
+            for (int k = i; k < 15; ++k) QLE_PS(i, k) -= h[i] * s[k];
+        }
+#pragma unroll
+        for (int k = 0; k < 15; ++k) dx[k] += s[k] * yc;
+#pragma unroll
+        for (int j = c + 1; j < 6; ++j) {
+            T l = S[c][j] * invd;
+#pragma unroll
+            for (int k = 0; k < 15; ++k) H[k][j] -= h[k] * l;
+            dy[j] -= l * yc;
+#pragma unroll
+            for (int j2 = j; j2 < 6; ++j2) S[j][j2] -= l * S[c][j2];
+        }
+    }
+
+    // inject, EKF.cpp:486-501
+    T dth[3] = {dx[6], dx[7], dx[8]}, qe[4], qn[4];
+    quat_exp(dth, qe);
+    quat_mul(q, qe, qn);
+    quat_norm(qn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x[i] = r[i] + dx[i];
+        x[3 + i] += dx[3 + i];
+        x[10 + i] = p.bias_on * (x[10 + i] + dx[9 + i]);
+        x[13 + i] = p.bias_on * (x[13 + i] + dx[12 + i]);
+    }
+    x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+}
+
+}  // namespace qle

@@ -1,0 +1,222 @@
+"""Host-side mirror of the reference filter interface over the C-ABI.
+
+`BatchedRelativePoseEKF` keeps the names and argument meaning of the
+reference's `class RelativePoseEKF` (quad_state_estimation/include/
+relative_pose_EKF.hpp:20-141; Python twin test/rel_pose_EKF_test_class.py)
+for a batch of independent filters resident on one MI355X:
+
+    reference (one filter, Eigen)                 here (B filters, numpy in/out)
+    prediction_step(x, P, u, &x', &P', &accel)    prediction_step(x, P, u) -> x', P', accel
+    correction_step(x, P, r_c_tc, q_ct, &x, &P)   correction_step(x, P, r_c_tc, q_ct) -> x, P
+    initialize_state(reinit_bias)                 initialize_state(z, reinit_bias)
+    initialize_params()                           initialize_params()
+    filter_update(t) single-rate tick             step(u, z, mask) / run(inputs, t0, n)
+
+All compute happens in the HIP kernels behind libqle_ekf.so; nothing here
+computes filter arithmetic.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import params as _params
+from ._lib import QLE_F32, QLE_F64, QleSynthCfg, check, lib
+
+_pd = C.POINTER(C.c_double)
+_pu8 = C.POINTER(C.c_uint8)
+
+
+def _dp(a):
+    return None if a is None else a.ctypes.data_as(_pd)
+
+
+def _f64(a, shape):
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+def _u8(a, shape):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if a.shape != tuple(shape):
+        raise ValueError(f"expected mask shape {tuple(shape)}, got {a.shape}")
+    return a
+
+
+class InputSequence:
+    """Device-resident IMU / tag-pose sequence (`qle_inputs`)."""
+
+    def __init__(self, ekf, n_ticks, tick_has_meas=None):
+        self.ekf = ekf
+        self.n_ticks = int(n_ticks)
+        thm = np.zeros(self.n_ticks, dtype=np.uint8) if tick_has_meas is None else _u8(tick_has_meas, (self.n_ticks,))
+        self.tick_has_meas = thm.copy()
+        self._h = C.c_void_p()
+        check(lib().qle_inputs_create(ekf._h, self.n_ticks, thm.ctypes.data_as(_pu8), C.byref(self._h)))
+
+    def upload_tick(self, t, u, z=None, mask=None):
+        B = self.ekf.batch
+        u = _f64(u, (B, 6))
+        z = None if z is None else _f64(z, (B, 7))
+        mask = _u8(mask, (B,))
+        check(lib().qle_inputs_upload_tick(self._h, int(t), _dp(u), _dp(z), None if mask is None else mask.ctypes.data_as(_pu8)))
+
+    def download_tick(self, t):
+        B = self.ekf.batch
+        u = np.empty((B, 6)); z = np.zeros((B, 7)); m = np.zeros(B, dtype=np.uint8)
+        check(lib().qle_inputs_download_tick(self._h, int(t), _dp(u), _dp(z), m.ctypes.data_as(_pu8)))
+        return u, z, m
+
+    def close(self):
+        if self._h:
+            lib().qle_inputs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchedRelativePoseEKF:
+    def __init__(self, batch, dtype="f32", device=0, params=None, **param_overrides):
+        self.batch = int(batch)
+        self.dtype = {"f32": QLE_F32, "fp32": QLE_F32, "float32": QLE_F32, "f64": QLE_F64, "fp64": QLE_F64,
+                      "float64": QLE_F64}[str(dtype)]
+        self.device = int(device)
+        self.params = params if params is not None else _params.default_params()
+        _params.set_fields(self.params, **param_overrides)
+        self._h = C.c_void_p()
+        check(lib().qle_create(C.byref(self._h), self.batch, self.dtype, self.device, C.byref(self.params)))
+        self.derived = _params.derive(self.params)
+
+    # ---- lifetime
+    def close(self):
+        if self._h:
+            lib().qle_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters
+    @property
+    def num_states(self):
+        return int(self.derived.num_states)
+
+    def initialize_params(self, **param_overrides):
+        """RelativePoseEKF::initialize_params (relative_pose_EKF.cpp:87-125) after changing public members."""
+        _params.set_fields(self.params, **param_overrides)
+        check(lib().qle_set_params(self._h, C.byref(self.params)))
+        self.derived = _params.derive(self.params)
+
+    def set_filter_params(self, pfp):
+        """Per-filter [Q diag 12, ab_static 3, wb_static 3, R diag 6]; None = shared parameters."""
+        check(lib().qle_set_filter_params(self._h, None if pfp is None else _dp(_f64(pfp, (self.batch, 24)))))
+
+    # ---- state
+    def set_state(self, x, P):
+        n = self.num_states
+        check(lib().qle_set_state(self._h, _dp(_f64(x, (self.batch, 16))), _dp(_f64(P, (self.batch, n, n)))))
+
+    def get_state(self):
+        n = self.num_states
+        x = np.empty((self.batch, 16)); P = np.empty((self.batch, n, n))
+        check(lib().qle_get_state(self._h, _dp(x), _dp(P)))
+        return x, P
+
+    def initialize_state(self, z, reinit_bias=False):
+        """RelativePoseEKF::initialize_state (relative_pose_EKF.cpp:305-344) from each filter's first tag pose."""
+        check(lib().qle_initialize_state(self._h, _dp(_f64(z, (self.batch, 7))), int(bool(reinit_bias))))
+
+    def enable_aux(self, on=True):
+        check(lib().qle_enable_aux(self._h, int(bool(on))))
+
+    def get_aux(self):
+        acc = np.empty((self.batch, 3)); obs = np.empty((self.batch, 7))
+        check(lib().qle_get_aux(self._h, _dp(acc), _dp(obs)))
+        return acc, obs
+
+    # ---- hot path on the resident state
+    def predict(self, u):
+        check(lib().qle_predict(self._h, _dp(_f64(u, (self.batch, 6)))))
+
+    def update(self, z, mask=None):
+        m = _u8(mask, (self.batch,))
+        check(lib().qle_update(self._h, _dp(_f64(z, (self.batch, 7))), None if m is None else m.ctypes.data_as(_pu8)))
+
+    def step(self, u, z=None, mask=None):
+        """One single-rate filter_update tick (relative_pose_EKF.cpp:238-249,265-290)."""
+        m = _u8(mask, (self.batch,))
+        zz = None if z is None else _f64(z, (self.batch, 7))
+        check(lib().qle_step(self._h, _dp(_f64(u, (self.batch, 6))), _dp(zz), None if m is None else m.ctypes.data_as(_pu8)))
+
+    # ---- reference-shaped value-in / value-out calls
+    def prediction_step(self, x_km1, P_km1, u):
+        """prediction_step(x_km1, P_km1, u) -> (x_check, P_check, pose_accel)   (relative_pose_EKF.cpp:346-415)."""
+        self.set_state(x_km1, P_km1)
+        self.enable_aux(True)
+        self.predict(u)
+        x, P = self.get_state()
+        return x, P, self.get_aux()[0]
+
+    def correction_step(self, x_check, P_check, r_c_tc, q_ct):
+        """correction_step(x_check, P_check, r_c_tc, q_ct) -> (x_hat, P_hat)   (relative_pose_EKF.cpp:417-502)."""
+        self.set_state(x_check, P_check)
+        z = np.concatenate([_f64(r_c_tc, (self.batch, 3)), _f64(q_ct, (self.batch, 4))], axis=1)
+        self.update(z)
+        return self.get_state()
+
+    # ---- device-resident sequences
+    def make_inputs(self, n_ticks, tick_has_meas=None):
+        return InputSequence(self, n_ticks, tick_has_meas)
+
+    def run(self, inputs, t0, n):
+        check(lib().qle_run(self._h, inputs._h, int(t0), int(n)))
+
+    def synth_generate(self, inputs, seed, filter_offset=0, perturb_filter_params=False, **kw):
+        c = QleSynthCfg()
+        check(lib().qle_synth_cfg_default(C.byref(c)))
+        c.seed = int(seed); c.filter_offset = int(filter_offset); c.perturb_filter_params = int(bool(perturb_filter_params))
+        for k, v in kw.items():
+            setattr(c, k, v)
+        check(lib().qle_synth_generate(self._h, inputs._h, C.byref(c)))
+
+    def synth_rmse(self, inputs):
+        out = np.zeros(3)
+        check(lib().qle_synth_rmse(self._h, inputs._h, _dp(out)))
+        return out
+
+    # ---- reporting / control
+    def report(self):
+        """What the node publishes after a tick (relative_pose_EKF_node.cpp:192-220)."""
+        B = self.batch
+        pose = np.empty((B, 7)); cov = np.empty((B, 36)); vel = np.empty((B, 3)); bias = np.empty((B, 6))
+        check(lib().qle_get_report(self._h, _dp(pose), _dp(cov), _dp(vel), _dp(bias)))
+        return {"pose": pose, "pose_cov": cov.reshape(B, 6, 6), "vel": vel, "bias": bias}
+
+    def count_nonfinite(self):
+        c = C.c_int64(0)
+        check(lib().qle_count_nonfinite(self._h, C.byref(c)))
+        return int(c.value)
+
+    def synchronize(self):
+        check(lib().qle_synchronize(self._h))
+
+    def timer_begin(self):
+        check(lib().qle_timer_begin(self._h))
+
+    def timer_end(self):
+        ms = C.c_float(0)
+        check(lib().qle_timer_end(self._h, C.byref(ms)))
+        return float(ms.value)
+
+    def algorithmic_bytes(self, kind):
+        return int(lib().qle_algorithmic_bytes(self._h, int(kind)))

@@ -1,0 +1,119 @@
+"""Shared helpers for the parity tests (oracle <-> engine)."""
+import json
+import math
+import os
+
+import numpy as np
+
+import oracle
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def param_sets():
+    return json.load(open(os.path.join(GOLDEN, "param_sets.json")))
+
+
+def golden_kwargs(ps, **over):
+    """Keyword set valid for both oracle.make_params and quadrotor_landing_amd.make_params."""
+    s = param_sets()[ps]
+    q = s["Q"]
+    kw = dict(update_freq=s["update_freq"], est_bias=int(s["est_bias"]), direct_orien_method=1,
+              Q_a=q[0:3], Q_w=q[3:6], R_r=s["R"][0:3], R_ang=s["R"][3:6], r_v_cv=s["r_v_cv"], q_vc=s["q_vc"])
+    if s["est_bias"]:
+        kw.update(Q_ab=q[6:9], Q_wb=q[9:12])
+    kw.update(over)
+    return kw
+
+
+def rand_quat(rng, n, max_angle=None):
+    if max_angle is None:
+        q = rng.normal(size=(n, 4))
+        q /= np.linalg.norm(q, axis=1, keepdims=True)
+        q[q[:, 3] < 0] *= -1
+        return q
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(0, max_angle, size=(n, 1))
+    return np.concatenate([ax * np.sin(ang / 2), np.cos(ang / 2)], axis=1)
+
+
+def rand_states(rng, B, n, cov_scale=1.0):
+    x = np.zeros((B, 16))
+    x[:, 0:3] = rng.uniform([-1, -1, 1], [1, 1, 4], size=(B, 3))
+    x[:, 3:6] = rng.normal(size=(B, 3)) * 0.5
+    x[:, 6:10] = rand_quat(rng, B)
+    if n == 15:
+        x[:, 10:13] = rng.normal(size=(B, 3)) * 0.1
+        x[:, 13:16] = rng.normal(size=(B, 3)) * 0.01
+    A = rng.normal(size=(B, n, n)) * 0.1
+    P = A @ A.transpose(0, 2, 1) + np.eye(n) * rng.uniform(0.01, 0.2, size=(B, n, 1))
+    P = 0.5 * (P + P.transpose(0, 2, 1)) * cov_scale
+    return x, P
+
+
+def rand_imu(rng, B):
+    u = np.zeros((B, 6))
+    u[:, 0:3] = rng.normal(size=(B, 3)) * 1.5 + np.array([0, 0, 9.8])
+    u[:, 3:6] = rng.normal(size=(B, 3)) * 0.4
+    return u
+
+
+def qmul(a, b):
+    av, aw, bv, bw = a[..., :3], a[..., 3:4], b[..., :3], b[..., 3:4]
+    return np.concatenate([aw * bv + bw * av + np.cross(av, bv), aw * bw - np.sum(av * bv, axis=-1, keepdims=True)], axis=-1)
+
+
+def qconj(q):
+    return q * np.array([-1, -1, -1, 1.0])
+
+
+def rot(q):
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    return np.stack([
+        np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], -1),
+        np.stack([2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)], -1),
+        np.stack([2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)], -1)], -2)
+
+
+def meas_near(rng, orc_p, x, ang=0.8, pos=0.1):
+    """Tag poses whose implied pose is near state x (inverse of EKF.cpp:431-438)."""
+    B = x.shape[0]
+    q_vc = np.array(list(orc_p.q_vc)); C_vc = np.array(list(orc_p.C_vc)).reshape(3, 3); r_v_cv = np.array(list(orc_p.r_v_cv))
+    q_true = qmul(x[:, 6:10], rand_quat(rng, B, ang))
+    r_true = x[:, 0:3] + rng.normal(size=(B, 3)) * pos
+    q_ct = qmul(qconj(q_vc)[None], qconj(q_true))
+    t = -np.einsum("bji,bj->bi", rot(q_true), r_true) - r_v_cv
+    r_c = t @ C_vc  # C_vc^T t
+    return np.concatenate([r_c, q_ct], axis=1)
+
+
+def oracle_predict_batch(p, x, P, u):
+    xo = np.empty_like(x); Po = np.empty_like(P); acc = np.empty((x.shape[0], 3))
+    for i in range(x.shape[0]):
+        xo[i], Po[i], acc[i] = oracle.prediction_step(p, x[i], P[i], u[i])
+    return xo, Po, acc
+
+
+def oracle_update_batch(p, x, P, z, mask=None):
+    xo = x.copy(); Po = P.copy()
+    obs = np.zeros((x.shape[0], 7))
+    for i in range(x.shape[0]):
+        if mask is None or mask[i]:
+            xo[i], Po[i], obs[i, :3], obs[i, 3:] = oracle.correction_step(p, x[i], P[i], z[i, :3], z[i, 3:])
+    return xo, Po, obs
+
+
+def quat_err(a, b):
+    """max over batch of min(|a-b|, |a+b|) per quaternion (sign-insensitive)."""
+    return np.minimum(np.abs(a - b).max(axis=-1), np.abs(a + b).max(axis=-1)).max()
+
+
+def assert_state_close(x, P, xr, Pr, rtol, atol, qtol=None):
+    qtol = qtol if qtol is not None else max(atol, rtol) * 10
+    assert quat_err(x[:, 6:10], xr[:, 6:10]) <= qtol, quat_err(x[:, 6:10], xr[:, 6:10])
+    keep = [i for i in range(16) if not 6 <= i < 10]
+    np.testing.assert_allclose(x[:, keep], xr[:, keep], rtol=rtol, atol=atol)
+    # covariance: tolerance relative to the scale of the matrix (entries near zero are sums of O(diag) terms)
+    scale = np.sqrt(np.einsum("bii->bi", Pr)[:, :, None] * np.einsum("bii->bi", Pr)[:, None, :])
+    err = np.abs(P - Pr) / (scale + 1e-300)
+    assert err.max() <= rtol * 50 + 0 * atol, err.max()
