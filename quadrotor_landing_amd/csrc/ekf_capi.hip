@@ -135,7 +135,7 @@ struct qle_batch {
     int64_t B = 0;
     int32_t dtype = QLE_F32;
     int32_t device = 0;
-    int32_t block = 64;
+    int32_t block = 256;
     size_t wsz = 4;
     qle_params pub;
     qle_derived der;
@@ -159,7 +159,8 @@ struct qle_batch {
 };
 
 struct qle_inputs {
-    qle_batch* h = nullptr;
+    qle_batch* h = nullptr;  // owner; only dereferenced by calls that also take the handle or run before its destroy
+    int32_t device = 0;      // copied so that destroy never touches the (possibly already destroyed) handle
     int64_t T = 0;
     int64_t n_slots = 0;
     std::vector<int32_t> slot;  // per tick: measurement slot or -1
@@ -197,6 +198,7 @@ static inline dim3 grid_for(const qle_batch* h, int block) { return dim3((unsign
 static int check_handle(const qle_batch* h)
 {
     if (!h) return fail(QLE_ERR_INVALID, "handle is null");
+    (void)hipGetLastError();  // drop any stale sticky error of this thread: launches below check their own
     hipError_t e = hipSetDevice(h->device);
     if (e != hipSuccess) return fail(QLE_ERR_HIP, "hipSetDevice(%d): %s", h->device, hipGetErrorString(e));
     return QLE_OK;
@@ -323,8 +325,6 @@ static int pack_rows(qle_batch* h, const double* host, int stride, int W, void* 
     for (int64_t i0 = 0; i0 < h->B; i0 += chunk) {
         const int64_t n = std::min(chunk, h->B - i0);
         HIP_TRY(hipMemcpyAsync(h->stage, host + i0 * stride, (size_t)n * stride * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        // dst + i0 words: word_off is linear in i for a fixed row, so shifting the base by i0*VW
-        // words addresses filters [i0, i0+n) of every row while keeping pitch B.
         hipLaunchKernelGGL((k_pack_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->stage, stride, W,
                            (T*)dst, h->B, i0, n);
         HIP_TRY(hipGetLastError());
@@ -623,7 +623,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 extern "C" int qle_inputs_destroy(qle_inputs* in)
 {
     if (!in) return QLE_OK;
-    if (in->h) (void)hipSetDevice(in->h->device);
+    (void)hipSetDevice(in->device);
     void* bufs[] = {in->u, in->z, in->truth, in->truth_bias};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -640,6 +640,7 @@ extern "C" int qle_inputs_create(qle_batch* h, int64_t n_ticks, const uint8_t* t
     qle_inputs* in = new (std::nothrow) qle_inputs();
     if (!in) return fail(QLE_ERR_NOMEM, "host allocation failed");
     in->h = h;
+    in->device = h->device;
     in->T = n_ticks;
     in->slot.assign((size_t)n_ticks, -1);
     for (int64_t t = 0; t < n_ticks; ++t)

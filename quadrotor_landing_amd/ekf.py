@@ -16,6 +16,7 @@ All compute happens in the HIP kernels behind libqle_ekf.so; nothing here
 computes filter arithmetic.
 """
 import ctypes as C
+import weakref
 
 import numpy as np
 
@@ -56,6 +57,7 @@ class InputSequence:
         self.tick_has_meas = thm.copy()
         self._h = C.c_void_p()
         check(lib().qle_inputs_create(ekf._h, self.n_ticks, thm.ctypes.data_as(_pu8), C.byref(self._h)))
+        ekf._sequences.append(weakref.ref(self))
 
     def upload_tick(self, t, u, z=None, mask=None):
         B = self.ekf.batch
@@ -91,11 +93,17 @@ class BatchedRelativePoseEKF:
         self.params = params if params is not None else _params.default_params()
         _params.set_fields(self.params, **param_overrides)
         self._h = C.c_void_p()
+        self._sequences = []
         check(lib().qle_create(C.byref(self._h), self.batch, self.dtype, self.device, C.byref(self.params)))
         self.derived = _params.derive(self.params)
 
     # ---- lifetime
     def close(self):
+        for ref in getattr(self, "_sequences", []):  # sequences live in this handle's device context
+            seq = ref()
+            if seq is not None:
+                seq.close()
+        self._sequences = []
         if self._h:
             lib().qle_destroy(self._h)
             self._h = C.c_void_p()

@@ -360,7 +360,10 @@ def test_cfg3_full_size_properties_fp32():
     assert ev.min() > 0                                           # P stays positive definite
     assert (np.einsum("bii->b", Pg) < np.einsum("bii->b", P0)).all()  # information gained
     er, eth, cnt = ekf.synth_rmse(seq)
-    assert cnt == B and np.sqrt(er / cnt) < 0.1 and np.sqrt(eth / cnt) < 0.1
+    # the filtered pose beats the raw tag measurement noise (R_r, R_ang of the ROTORS set)
+    assert cnt == B
+    assert np.sqrt(er / cnt) < 0.75 * np.sqrt(0.015 + 0.015 + 0.020)
+    assert np.sqrt(eth / cnt) < 0.75 * np.sqrt(0.0015 + 0.0015 + 0.04)
     # a strided sample of 256 filters against the fp64 oracle over the whole run
     idx = np.arange(0, B, 256)
     U = np.empty((T, idx.size, 6)); Z = np.zeros((T, idx.size, 7)); M = np.zeros((T, idx.size), np.uint8)
