@@ -34,6 +34,26 @@ CFG3 = dict(update_freq=400.0, measurement_freq=30.0, limit_measurement_freq=1, 
             R_r=[0.015, 0.015, 0.020], R_ang=[0.0015, 0.0015, 0.04])
 
 
+def cpu_share():
+    """CPUs this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(float(txt[0]) / float(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / per + 0.5)))
+            break
+        except Exception:
+            continue
+    return n
+
+
 def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
     """Oracle (reference-shaped dense fp64 C restatement) timed on this host's cores
     on a bounded sample of the same workload.  Reported baseline, not the target."""
@@ -43,11 +63,11 @@ def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
     for t in range(n_ticks):
         u, z, m = seq.download_tick(t)
         U[t], Z[t], M[t] = u[:n_filters], z[:n_filters], m[:n_filters]
-    nthr = oracle.max_threads()
+    nthr = max(1, min(oracle.max_threads(), cpu_share()))
     t0 = time.perf_counter()
     oracle.run_batch(po, x0[:n_filters], P0[:n_filters], U, Z, M, n_threads=nthr)
     dt_all = time.perf_counter() - t0
-    n1 = max(n_filters // 16, 64)
+    n1 = max(n_filters // 64, 64)
     t0 = time.perf_counter()
     oracle.run_batch(po, x0[:n1], P0[:n1], U[:, :n1], Z[:, :n1], M[:, :n1], n_threads=1)
     dt_one = time.perf_counter() - t0
@@ -159,7 +179,7 @@ def main():
         "nonfinite_filters": bad,
     }
     if x0 is not None:
-        out["cpu_baseline"] = cpu_baseline(seq, x0, P0, 4096, 280)
+        out["cpu_baseline"] = cpu_baseline(seq, x0, P0, min(B, 65536), 140)
     if rank == 0:
         print(json.dumps(out), flush=True)
     ekf.close()

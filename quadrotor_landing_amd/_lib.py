@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libqle_ekf.so")
+# QLE_LIB selects an alternative in-tree build of the same engine (kernel tuning A/B runs)
+LIB_PATH = os.environ.get("QLE_LIB") or os.path.join(_HERE, "libqle_ekf.so")
 
 QLE_OK = 0
 QLE_ERR_INVALID, QLE_ERR_HIP, QLE_ERR_NOMEM, QLE_ERR_STATE, QLE_ERR_NO_DEVICE = -1, -2, -3, -4, -5

@@ -143,9 +143,9 @@ struct qle_batch {
     DevParams<double> pd;
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    void* x = nullptr;     // [16 words] quad rows
-    void* P = nullptr;     // [120 words] quad rows
-    void* pfp = nullptr;   // [24 words] quad rows, per-filter params
+    int64_t Bp = 0;        // batch padded to whole 64-filter tiles
+    void* st = nullptr;    // state records: x (16 words) + packed P (120 words), wave tiles
+    void* pfp = nullptr;   // [24 words] per-filter params, wave tiles
     bool pfp_on = false;
     bool aux = false;
     void* aux_accel = nullptr;  // AoS [B][3], compute dtype
@@ -222,7 +222,7 @@ extern "C" int qle_destroy(qle_batch* h)
     if (!h) return QLE_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->x, h->P, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter};
+    void* bufs[] = {h->st, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -248,6 +248,7 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     qle_batch* h = new (std::nothrow) qle_batch();
     if (!h) return fail(QLE_ERR_NOMEM, "host allocation failed");
     h->B = batch;
+    h->Bp = padded_filters(batch);
     h->dtype = dtype;
     h->device = device;
     h->wsz = dtype == QLE_F32 ? 4 : 8;
@@ -266,17 +267,15 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     } while (0)
     if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipEventCreate failed"));
-    const size_t B = (size_t)batch, w = h->wsz;
-    ALLOC(h->x, kXW * B * w);
-    ALLOC(h->P, kPW * B * w);
-    ALLOC(h->tick_u, kUW * B * w + 256);
+    const size_t B = (size_t)h->Bp, w = h->wsz;
+    ALLOC(h->st, kSW * B * w);
+    ALLOC(h->tick_u, kUW * B * w);
     ALLOC(h->tick_z, kZW * B * w);
     ALLOC(h->stage, (size_t)kStageDoubles * sizeof(double));
     ALLOC(h->stage_mask, (size_t)kStageFilters);
     ALLOC(h->counter, sizeof(unsigned long long));
 #undef ALLOC
-    if (hipMemsetAsync(h->x, 0, kXW * B * w, h->stream) != hipSuccess || hipMemsetAsync(h->P, 0, kPW * B * w, h->stream) != hipSuccess)
-        return bail(fail(QLE_ERR_HIP, "hipMemsetAsync failed"));
+    if (hipMemsetAsync(h->st, 0, kSW * B * w, h->stream) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipMemsetAsync failed"));
     *out = h;
     return QLE_OK;
 }
@@ -316,30 +315,30 @@ extern "C" int qle_timer_end(qle_batch* h, float* ms)
 }
 
 // --------------------------------------------------- staging (not hot path)
-// Chunked AoS fp64 host -> device quad rows.  `W` words per filter taken from
-// a host row of `stride` doubles; dst rows have pitch B and start at filter 0.
+// Chunked AoS fp64 host -> device tiles.  `W` words per filter taken from a
+// host row of `stride` doubles go to words [w0, w0+W) of the WT-word record.
 template <typename T>
-static int pack_rows(qle_batch* h, const double* host, int stride, int W, void* dst)
+static int pack_rows(qle_batch* h, const double* host, int stride, int W, void* dst, int WT, int w0)
 {
     const int64_t chunk = std::min<int64_t>(kStageFilters, kStageDoubles / std::max(stride, 1));
     for (int64_t i0 = 0; i0 < h->B; i0 += chunk) {
         const int64_t n = std::min(chunk, h->B - i0);
         HIP_TRY(hipMemcpyAsync(h->stage, host + i0 * stride, (size_t)n * stride * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL((k_pack_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->stage, stride, W,
-                           (T*)dst, h->B, i0, n);
+                           (T*)dst, WT, w0, i0, n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));  // staging buffer is reused by the next chunk
     }
     return QLE_OK;
 }
 template <typename T>
-static int unpack_rows(qle_batch* h, const void* src, int stride, int W, double* host)
+static int unpack_rows(qle_batch* h, const void* src, int stride, int W, double* host, int WT, int w0)
 {
     const int64_t chunk = std::min<int64_t>(kStageFilters, kStageDoubles / std::max(stride, 1));
     for (int64_t i0 = 0; i0 < h->B; i0 += chunk) {
         const int64_t n = std::min(chunk, h->B - i0);
         hipLaunchKernelGGL((k_unpack_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, stride, W, h->stage,
-                           h->B, i0, n);
+                           WT, w0, i0, n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host + i0 * stride, h->stage, (size_t)n * stride * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -354,7 +353,7 @@ static int pack_z(qle_batch* h, const double* z, const uint8_t* mask, void* dst)
         if (z) HIP_TRY(hipMemcpyAsync(h->stage, z + i0 * 7, (size_t)n * 7 * sizeof(double), hipMemcpyHostToDevice, h->stream));
         if (mask) HIP_TRY(hipMemcpyAsync(h->stage_mask, mask + i0, (size_t)n, hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL((k_pack_z_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, z ? (const double*)h->stage : nullptr,
-                           mask ? (const uint8_t*)h->stage_mask : nullptr, (T*)dst, h->B, i0, n);
+                           mask ? (const uint8_t*)h->stage_mask : nullptr, (T*)dst, i0, n);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
@@ -368,7 +367,7 @@ static int pack_P(qle_batch* h, const double* P, void* dst)
         const int64_t m = std::min(kStageFilters, h->B - i0);
         HIP_TRY(hipMemcpyAsync(h->stage, P + i0 * n * n, (size_t)m * n * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL((k_pack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->stage, n, (T*)dst,
-                           h->B, i0, m);
+                           i0, m);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
@@ -380,8 +379,7 @@ static int unpack_P(qle_batch* h, const void* src, double* P)
     const int n = h->der.num_states;
     for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
         const int64_t m = std::min(kStageFilters, h->B - i0);
-        hipLaunchKernelGGL((k_unpack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, n, h->stage, h->B, i0,
-                           m);
+        hipLaunchKernelGGL((k_unpack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, n, h->stage, i0, m);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(P + i0 * n * n, h->stage, (size_t)m * n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -395,16 +393,16 @@ extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
 {
     QLE_TRY(check_handle(h));
     if (!x || !P) return fail(QLE_ERR_INVALID, "x and P must be non-null");
-    QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, h->x));
-    QLE_TRY(BY_DTYPE(h, pack_P, h, P, h->P));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, h->st, kSW, 0));
+    QLE_TRY(BY_DTYPE(h, pack_P, h, P, h->st));
     h->state_set = true;
     return QLE_OK;
 }
 extern "C" int qle_get_state(qle_batch* h, double* x, double* P)
 {
     QLE_TRY(check_handle(h));
-    if (x) QLE_TRY(BY_DTYPE(h, unpack_rows, h, h->x, kXW, kXW, x));
-    if (P) QLE_TRY(BY_DTYPE(h, unpack_P, h, h->P, P));
+    if (x) QLE_TRY(BY_DTYPE(h, unpack_rows, h, h->st, kXW, kXW, x, kSW, 0));
+    if (P) QLE_TRY(BY_DTYPE(h, unpack_P, h, h->st, P));
     return QLE_OK;
 }
 
@@ -412,8 +410,8 @@ extern "C" int qle_set_filter_params(qle_batch* h, const double* pfp)
 {
     QLE_TRY(check_handle(h));
     if (!pfp) { h->pfp_on = false; return QLE_OK; }
-    if (!h->pfp) HIP_TRY(hipMalloc(&h->pfp, kFW * (size_t)h->B * h->wsz));
-    QLE_TRY(BY_DTYPE(h, pack_rows, h, pfp, kFW, kFW, h->pfp));
+    if (!h->pfp) HIP_TRY(hipMalloc(&h->pfp, kFW * (size_t)h->Bp * h->wsz));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, pfp, kFW, kFW, h->pfp, kFW, 0));
     h->pfp_on = true;
     return QLE_OK;
 }
@@ -458,14 +456,14 @@ static int launch_predict(qle_batch* h, const void* u)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *x = (T*)h->x, *P = (T*)h->P, *acc = (T*)h->aux_accel;
+    T *st = (T*)h->st, *acc = (T*)h->aux_accel;
     const T* pfp = (const T*)h->pfp;
     if (h->pfp_on) {
-        if (h->aux) hipLaunchKernelGGL((k_predict<T, true, true>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
-        else hipLaunchKernelGGL((k_predict<T, true, false>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
+        if (h->aux) hipLaunchKernelGGL((k_predict<T, true, true>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+        else hipLaunchKernelGGL((k_predict<T, true, false>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
     } else {
-        if (h->aux) hipLaunchKernelGGL((k_predict<T, false, true>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
-        else hipLaunchKernelGGL((k_predict<T, false, false>), g, b, 0, h->stream, p, x, P, (const T*)u, pfp, acc, h->B);
+        if (h->aux) hipLaunchKernelGGL((k_predict<T, false, true>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+        else hipLaunchKernelGGL((k_predict<T, false, false>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
     }
     HIP_TRY(hipGetLastError());
     return QLE_OK;
@@ -476,14 +474,14 @@ static int launch_step_d(qle_batch* h, const void* u, const void* z)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *x = (T*)h->x, *P = (T*)h->P, *acc = (T*)h->aux_accel, *obs = (T*)h->aux_obs;
+    T *st = (T*)h->st, *acc = (T*)h->aux_accel, *obs = (T*)h->aux_obs;
     const T* pfp = (const T*)h->pfp;
     if (h->pfp_on) {
-        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, true, true>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
-        else hipLaunchKernelGGL((k_step<T, DIRECT, true, false>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, true, true>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+        else hipLaunchKernelGGL((k_step<T, DIRECT, true, false>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
     } else {
-        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, false, true>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
-        else hipLaunchKernelGGL((k_step<T, DIRECT, false, false>), g, b, 0, h->stream, p, x, P, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, false, true>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
+        else hipLaunchKernelGGL((k_step<T, DIRECT, false, false>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
     }
     HIP_TRY(hipGetLastError());
     return QLE_OK;
@@ -499,14 +497,14 @@ static int launch_update_d(qle_batch* h, const void* z)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *x = (T*)h->x, *P = (T*)h->P, *obs = (T*)h->aux_obs;
+    T *st = (T*)h->st, *obs = (T*)h->aux_obs;
     const T* pfp = (const T*)h->pfp;
     if (h->pfp_on) {
-        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, true, true>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
-        else hipLaunchKernelGGL((k_update<T, DIRECT, true, false>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
+        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, true, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
+        else hipLaunchKernelGGL((k_update<T, DIRECT, true, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
     } else {
-        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, false, true>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
-        else hipLaunchKernelGGL((k_update<T, DIRECT, false, false>), g, b, 0, h->stream, p, x, P, (const T*)z, pfp, obs, h->B);
+        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, false, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
+        else hipLaunchKernelGGL((k_update<T, DIRECT, false, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
     }
     HIP_TRY(hipGetLastError());
     return QLE_OK;
@@ -528,7 +526,7 @@ extern "C" int qle_predict(qle_batch* h, const double* u)
     QLE_TRY(check_handle(h));
     QLE_TRY(need_state(h));
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
-    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     return BY_DTYPE(h, launch_predict, h, h->tick_u);
 }
 extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)
@@ -544,7 +542,7 @@ extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const ui
     QLE_TRY(check_handle(h));
     QLE_TRY(need_state(h));
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
-    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     if (!z) return BY_DTYPE(h, launch_predict, h, h->tick_u);
     QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
     return BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z);
@@ -554,7 +552,7 @@ template <typename T>
 static int seed_t(qle_batch* h, int reinit)
 {
     const qle_derived& d = h->der;
-    hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)h->x, (T*)h->P,
+    hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)h->st,
                        (T)d.cov_init[0], (T)d.cov_init[3], (T)d.cov_init[6], (T)d.cov_init[9], (T)d.cov_init[12], reinit, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
@@ -580,8 +578,8 @@ static int report_t(qle_batch* h, double* pose, double* cov, double* vel, double
         double* s_cov = s_pose + n * 7;
         double* s_vel = s_cov + n * 36;
         double* s_bias = s_vel + n * 3;
-        hipLaunchKernelGGL((k_report_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->x, (const T*)h->P,
-                           h->pfp_on ? (const T*)h->pfp : (const T*)nullptr, s_pose, s_cov, s_vel, s_bias, h->B, i0, n);
+        hipLaunchKernelGGL((k_report_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->st,
+                           h->pfp_on ? (const T*)h->pfp : (const T*)nullptr, s_pose, s_cov, s_vel, s_bias, i0, n);
         HIP_TRY(hipGetLastError());
         if (pose) HIP_TRY(hipMemcpyAsync(pose + i0 * 7, s_pose, (size_t)n * 7 * 8, hipMemcpyDeviceToHost, h->stream));
         if (cov) HIP_TRY(hipMemcpyAsync(cov + i0 * 36, s_cov, (size_t)n * 36 * 8, hipMemcpyDeviceToHost, h->stream));
@@ -600,7 +598,7 @@ extern "C" int qle_get_report(qle_batch* h, double* pose, double* pose_cov, doub
 template <typename T>
 static int nonfinite_t(qle_batch* h)
 {
-    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->x, (const T*)h->P, h->counter, h->B);
+    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->st, h->counter, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
@@ -645,8 +643,8 @@ extern "C" int qle_inputs_create(qle_batch* h, int64_t n_ticks, const uint8_t* t
     in->slot.assign((size_t)n_ticks, -1);
     for (int64_t t = 0; t < n_ticks; ++t)
         if (tick_has_meas && tick_has_meas[t]) in->slot[(size_t)t] = (int32_t)in->n_slots++;
-    in->pitch_u = align_up(kUW * (size_t)h->B * h->wsz, 256);
-    in->pitch_z = align_up(kZW * (size_t)h->B * h->wsz, 256);
+    in->pitch_u = align_up(kUW * (size_t)h->Bp * h->wsz, 256);
+    in->pitch_z = align_up(kZW * (size_t)h->Bp * h->wsz, 256);
     hipError_t e = hipMalloc(&in->u, in->pitch_u * (size_t)n_ticks);
     if (e == hipSuccess && in->n_slots) e = hipMalloc(&in->z, in->pitch_z * (size_t)in->n_slots);
     if (e == hipSuccess) e = hipMalloc(&in->truth, (size_t)h->B * 7 * sizeof(double));
@@ -674,7 +672,7 @@ extern "C" int qle_inputs_upload_tick(qle_inputs* in, int64_t t, const double* u
     qle_batch* h = in->h;
     QLE_TRY(check_handle(h));
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
-    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, u_at(in, t)));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, u_at(in, t), kUW, 0));
     const int32_t s = in->slot[(size_t)t];
     if (s >= 0) {
         if (!z) return fail(QLE_ERR_INVALID, "tick %lld has a measurement slot but z is null", (long long)t);
@@ -691,7 +689,7 @@ static int unpack_z(qle_batch* h, const void* src, double* z, uint8_t* mask)
     for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
         const int64_t n = std::min(kStageFilters, h->B - i0);
         hipLaunchKernelGGL((k_unpack_z_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, h->stage, h->stage_mask,
-                           h->B, i0, n);
+                           i0, n);
         HIP_TRY(hipGetLastError());
         if (z) HIP_TRY(hipMemcpyAsync(z + i0 * 7, h->stage, (size_t)n * 7 * 8, hipMemcpyDeviceToHost, h->stream));
         if (mask) HIP_TRY(hipMemcpyAsync(mask + i0, h->stage_mask, (size_t)n, hipMemcpyDeviceToHost, h->stream));
@@ -704,7 +702,7 @@ extern "C" int qle_inputs_download_tick(qle_inputs* in, int64_t t, double* u, do
     QLE_TRY(check_tick(in, t));
     qle_batch* h = in->h;
     QLE_TRY(check_handle(h));
-    if (u) QLE_TRY(BY_DTYPE(h, unpack_rows, h, u_at(in, t), kUW, kUW, u));
+    if (u) QLE_TRY(BY_DTYPE(h, unpack_rows, h, u_at(in, t), kUW, kUW, u, kUW, 0));
     const int32_t s = in->slot[(size_t)t];
     if (s >= 0 && (z || mask)) QLE_TRY(BY_DTYPE(h, unpack_z, h, z_at(in, s), z, mask));
     if (s < 0 && mask) std::memset(mask, 0, (size_t)h->B);
@@ -766,7 +764,7 @@ static int synth_t(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
     HIP_TRY(hipMalloc((void**)&d_slot, sizeof(int32_t) * (size_t)in->T));
     hipError_t e = hipMemcpyAsync(d_slot, in->slot.data(), sizeof(int32_t) * (size_t)in->T, hipMemcpyHostToDevice, h->stream);
     if (e == hipSuccess) {
-        if (c->perturb_filter_params && !h->pfp) e = hipMalloc(&h->pfp, kFW * (size_t)h->B * h->wsz);
+        if (c->perturb_filter_params && !h->pfp) e = hipMalloc(&h->pfp, kFW * (size_t)h->Bp * h->wsz);
     }
     if (e == hipSuccess) {
         hipLaunchKernelGGL((k_synth<T>), grid_for(h, 64), dim3(64), 0, h->stream, a, (const int32_t*)d_slot, (T*)in->u, (T*)in->z, (T*)h->tick_z,
@@ -796,7 +794,7 @@ extern "C" int qle_synth_generate(qle_batch* h, qle_inputs* in, const qle_synth_
 template <typename T>
 static int rmse_t(qle_batch* h, const qle_inputs* in, double* d_out)
 {
-    hipLaunchKernelGGL((k_rmse<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->x, (const double*)in->truth, d_out, h->B);
+    hipLaunchKernelGGL((k_rmse<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->st, (const double*)in->truth, d_out, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }

@@ -14,10 +14,11 @@
 //   L3: th <- Rt th - dT wb                 (F[th,th], F[th,wb] EKF.cpp:383-395,400)
 // and P <- L3 (L2 (L1 P L1^T) L2^T) L3^T + W Q W^T is applied as three in-place
 // symmetric congruences on the packed upper triangle (~620 FMA instead of
-// ~7000).  The correction uses the LDL^T (square-root-free Cholesky) form of
-// K = P G^T S^-1 and P <- P - (P G^T) S^-1 (P G^T)^T, one measurement
-// component at a time -- algebraically identical to EKF.cpp:475-481, different
-// rounding.  Every array index below is a compile-time constant after
+// ~7000).  The correction decorrelates the 6-D measurement (LDL^T of
+// R_k = N R N^T) and then fuses its six components one scalar at a time,
+// P <- P - h h^T / s with h read from the live covariance -- algebraically
+// identical to K = P G^T S^-1, P <- (I - K G) P of EKF.cpp:475-481, different
+// rounding, and no 15x6 copy of P G^T in registers.  Every array index below is a compile-time constant after
 // unrolling, so nothing lives in scratch memory.
 #pragma once
 
@@ -381,9 +382,15 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
         dy[3] = dth[0]; dy[4] = dth[1]; dy[5] = dth[2];
     }
 
-    // H = P G^T (15x6), G = [I 0 Gx 0 0; 0 0 I 0 0], Gx = Cc [Cc^T r]x unless direct (EKF.cpp:453-459)
-    T H[15][6];
-    T Gx[3][3];
+    // G restricted to the six state columns it touches, J = {r0,r1,r2,th0,th1,th2} = {0,1,2,6,7,8}:
+    //   G = [I Gx; 0 I] over J, Gx = Cc [Cc^T r]x unless direct (EKF.cpp:453-459).
+    constexpr int J[6] = {0, 1, 2, 6, 7, 8};
+    T Gm[6][6];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+#pragma unroll
+        for (int b = 0; b < 6; ++b) Gm[a][b] = (a == b) ? T(1) : T(0);
+    }
     if (!DIRECT) {
         T b[3];
 #pragma unroll
@@ -391,43 +398,22 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             T c0 = Cc[3 * i], c1 = Cc[3 * i + 1], c2 = Cc[3 * i + 2];
-            Gx[i][0] = c1 * b[2] - c2 * b[1];
-            Gx[i][1] = c2 * b[0] - c0 * b[2];
-            Gx[i][2] = c0 * b[1] - c1 * b[0];
+            Gm[i][3] = c1 * b[2] - c2 * b[1];
+            Gm[i][4] = c2 * b[0] - c0 * b[2];
+            Gm[i][5] = c0 * b[1] - c1 * b[0];
         }
     }
-#pragma unroll
-    for (int k = 0; k < 15; ++k) {
-#pragma unroll
-        for (int a = 0; a < 3; ++a) {
-            H[k][3 + a] = QLE_PS(k, 6 + a);
-            T s = QLE_PS(k, a);
-            if (!DIRECT) s += Gx[a][0] * QLE_PS(k, 6) + Gx[a][1] * QLE_PS(k, 7) + Gx[a][2] * QLE_PS(k, 8);
-            H[k][a] = s;
-        }
-    }
-    // S = G H + R_k (upper triangle), R_k = N R N^T (EKF.cpp:462-472)
-    T S[6][6];
-#pragma unroll
-    for (int a = 0; a < 3; ++a) {
-#pragma unroll
-        for (int b = a; b < 6; ++b) {
-            T s = H[a][b];
-            if (!DIRECT) s += Gx[a][0] * H[6][b] + Gx[a][1] * H[7][b] + Gx[a][2] * H[8][b];
-            S[a][b] = s;
-        }
-#pragma unroll
-        for (int b = a; b < 3; ++b) S[3 + a][3 + b] = H[6 + a][3 + b];
-    }
+    // R_k = N R N^T (upper triangle), N = [-Cc C_vc, [r]x (direct) ; 0, C_vc]  (EKF.cpp:462-472)
+    T Rk[6][6];
     {
-        T N00[3][3];  // -Cc C_vc
+        T N00[3][3];
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int j = 0; j < 3; ++j)
                 N00[i][j] = -(Cc[3 * i] * p.C_vc[j] + Cc[3 * i + 1] * p.C_vc[3 + j] + Cc[3 * i + 2] * p.C_vc[6 + j]);
         }
-        // [r]x rows (EKF.cpp:465-468): row0 = (0,-r2,r1), row1 = (r2,0,-r0), row2 = (-r1,r0,0)
+        // [r]x rows (EKF.cpp:465-468): (0,-r2,r1), (r2,0,-r0), (-r1,r0,0)
         T Sr[3][3] = {{T(0), -r[2], r[1]}, {r[2], T(0), -r[0]}, {-r[1], r[0], T(0)}};
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -435,46 +421,65 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
             for (int j = i; j < 3; ++j) {
                 T s = N00[i][0] * nz.R[0] * N00[j][0] + N00[i][1] * nz.R[1] * N00[j][1] + N00[i][2] * nz.R[2] * N00[j][2];
                 if (DIRECT) s += Sr[i][0] * nz.R[3] * Sr[j][0] + Sr[i][1] * nz.R[4] * Sr[j][1] + Sr[i][2] * nz.R[5] * Sr[j][2];
-                S[i][j] += s;
-                S[3 + i][3 + j] += p.C_vc[3 * i] * nz.R[3] * p.C_vc[3 * j] + p.C_vc[3 * i + 1] * nz.R[4] * p.C_vc[3 * j + 1] +
+                Rk[i][j] = s;
+                Rk[3 + i][3 + j] = p.C_vc[3 * i] * nz.R[3] * p.C_vc[3 * j] + p.C_vc[3 * i + 1] * nz.R[4] * p.C_vc[3 * j + 1] +
                                    p.C_vc[3 * i + 2] * nz.R[5] * p.C_vc[3 * j + 2];
             }
-            if (DIRECT) {
 #pragma unroll
-                for (int j = 0; j < 3; ++j)
-                    S[i][3 + j] += Sr[i][0] * nz.R[3] * p.C_vc[3 * j] + Sr[i][1] * nz.R[4] * p.C_vc[3 * j + 1] +
-                                   Sr[i][2] * nz.R[5] * p.C_vc[3 * j + 2];
-            }
+            for (int j = 0; j < 3; ++j)
+                Rk[i][3 + j] = DIRECT ? Sr[i][0] * nz.R[3] * p.C_vc[3 * j] + Sr[i][1] * nz.R[4] * p.C_vc[3 * j + 1] +
+                                            Sr[i][2] * nz.R[5] * p.C_vc[3 * j + 2]
+                                      : T(0);
         }
     }
-
-    // LDL^T sweep over the 6 measurement components: after component c,
-    // P, H, S, dy hold the problem conditioned on components 0..c.
+    // Decorrelate the measurement: R_k = L D L^T (unit lower L); y' = L^-1 dy, G' = L^-1 G,
+    // R' = D is diagonal, so the six components can be fused one scalar at a time and
+    // h = P g'^T is read from the live covariance (no 15x6 copy of P G^T is kept).
+    // In the direct method G' stays unit lower triangular: only entries m <= c are touched.
+    T d[6];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+        d[c] = Rk[c][c];
+        const T invd = T(1) / d[c];
+#pragma unroll
+        for (int j = c + 1; j < 6; ++j) {
+            const T l = Rk[c][j] * invd;
+#pragma unroll
+            for (int j2 = j; j2 < 6; ++j2) Rk[j][j2] -= l * Rk[c][j2];
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+                if (!DIRECT || m <= c) Gm[j][m] -= l * Gm[c][m];
+            dy[j] -= l * dy[c];
+        }
+    }
+    // Six scalar updates (EKF.cpp:475-481 in sequential form): for component c
+    //   h = P g'_c^T, s = g'_c h + d_c, k = h/s, dx += k (y'_c - g'_c dx), P -= h k^T.
     T dx[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) dx[k] = T(0);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        T invd = T(1) / S[c][c];
-        T yc = dy[c];
-        T h[15], s[15];
+        T h[15];
 #pragma unroll
-        for (int k = 0; k < 15; ++k) { h[k] = H[k][c]; s[k] = h[k] * invd; }
+        for (int k = 0; k < 15; ++k) {
+            T acc = T(0);
+#pragma unroll
+            for (int m = 0; m < 6; ++m)
+                if (!DIRECT || m <= c) acc += Gm[c][m] * QLE_PS(k, J[m]);
+            h[k] = acc;
+        }
+        T s = d[c], nu = dy[c];
+#pragma unroll
+        for (int m = 0; m < 6; ++m)
+            if (!DIRECT || m <= c) { s += Gm[c][m] * h[J[m]]; nu -= Gm[c][m] * dx[J[m]]; }
+        const T inv = T(1) / s;
+        T kk[15];
+#pragma unroll
+        for (int k = 0; k < 15; ++k) { kk[k] = h[k] * inv; dx[k] += kk[k] * nu; }
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
 #pragma unroll
-            for (int k = i; k < 15; ++k) QLE_PS(i, k) -= h[i] * s[k];
-        }
-#pragma unroll
-        for (int k = 0; k < 15; ++k) dx[k] += s[k] * yc;
-#pragma unroll
-        for (int j = c + 1; j < 6; ++j) {
-            T l = S[c][j] * invd;
-#pragma unroll
-            for (int k = 0; k < 15; ++k) H[k][j] -= h[k] * l;
-            dy[j] -= l * yc;
-#pragma unroll
-            for (int j2 = j; j2 < 6; ++j2) S[j][j2] -= l * S[c][j2];
+            for (int k = i; k < 15; ++k) QLE_PS(i, k) -= h[i] * kk[k];
         }
     }
 

@@ -1,14 +1,21 @@
 // ekf_kernels.hpp -- HIP kernels of the batched EKF engine (gfx950).
 //
-// Data layout in HBM ("quad rows"): a per-filter record of W words of type T
-// is stored as rows of 16-byte quads, row k holding words [k*VW, (k+1)*VW) of
-// every filter (VW = 4 for fp32, 2 for fp64):
-//     addr(word w, filter i) = ((w / VW) * B + i) * VW + (w % VW)
-// so lane i of a wave reads one aligned 16-byte quad per row and a wave reads
-// 1 KiB contiguous (global_load_dwordx4 per lane, fully coalesced).  A record
-// whose length is not a multiple of VW (fp32 u: 6 words) ends in one row of
-// 8-byte halves.  One lane owns one filter; x (16 words) and the packed
-// symmetric P (120 words) live in VGPRs for the whole tick.
+// Data layout in HBM: "wave tiles".  The batch is cut into tiles of 64
+// consecutive filters (one wavefront).  A per-filter record of WT words of
+// type T is stored tile by tile; inside a tile it is stored as rows of 16-byte
+// quads, row k holding words [k*VW, (k+1)*VW) of the tile's 64 filters
+// (VW = 4 for fp32, 2 for fp64):
+//     off(word w, filter i) = (i/64)*WT*64 + ((w/VW)*64 + i%64)*VW + w%VW
+// Lane l of a wave reads one aligned 16-byte quad per row (global_load_dwordx4),
+// a row is 1 KiB contiguous, and the whole record of a wave is one contiguous
+// block (state: 136 words -> 34 KiB fp32 / 68 KiB fp64 per tile), so a wave
+// touches a handful of DRAM pages / TLB entries instead of one per row.
+// A record whose length is not a multiple of VW (fp32 u: 6 words) ends in one
+// row of 8-byte halves.
+//
+// The filter state is ONE record of 136 words: x (16) followed by the packed
+// upper triangle of P (120).  One lane owns one filter; the record lives in
+// VGPRs for the whole tick.
 #pragma once
 
 #include "ekf_device.hpp"
@@ -16,11 +23,21 @@
 namespace qle {
 
 constexpr int kBlock = 256;
-constexpr int kXW = 16;   // state words
-constexpr int kPW = 120;  // packed covariance words
-constexpr int kUW = 6;    // IMU words
-constexpr int kZW = 8;    // tag pose 7 words + mask word
-constexpr int kFW = 24;   // per-filter parameter words
+constexpr int kTile = 64;   // filters per tile = wavefront size
+
+// Minimum waves per SIMD the predict kernel is compiled for (register budget 512/waves).
+// Measured on MI355X (profiles/r01_sweep.md): forcing two waves for fp32 costs 16 spilled VGPRs
+// (68 B/lane of scratch traffic) and is slower at every batch size, so the default is one.
+#ifndef QLE_PREDICT_WAVES_F32
+#define QLE_PREDICT_WAVES_F32 1
+#endif
+template <typename T> struct PredictWaves { static constexpr int value = sizeof(T) == 4 ? QLE_PREDICT_WAVES_F32 : 1; };
+constexpr int kXW = 16;     // state words
+constexpr int kPW = 120;    // packed covariance words
+constexpr int kSW = kXW + kPW;  // state record
+constexpr int kUW = 6;      // IMU words
+constexpr int kZW = 8;      // tag pose 7 words + mask word
+constexpr int kFW = 24;     // per-filter parameter words
 
 template <typename T> struct Quad;
 template <> struct Quad<float> { using type = float4; static constexpr int VW = 4; };
@@ -31,57 +48,70 @@ __device__ __forceinline__ void unpack_quad(const double2& v, double* r) { r[0] 
 __device__ __forceinline__ float4 pack_quad(const float* r) { return make_float4(r[0], r[1], r[2], r[3]); }
 __device__ __forceinline__ double2 pack_quad(const double* r) { return make_double2(r[0], r[1]); }
 
-// Offset (in words) of word w of filter i in a W-word record array.
+// Number of filters a record array must be allocated for (whole tiles).
+__host__ __device__ inline int64_t padded_filters(int64_t B) { return (B + kTile - 1) / kTile * kTile; }
+
+// Offset (in words) of word w of filter i in an array of WT-word records.
 template <typename T>
-__host__ __device__ inline int64_t word_off(int w, int64_t i, int64_t B, int W)
+__host__ __device__ inline int64_t word_off(int w, int64_t i, int WT)
 {
     constexpr int VW = 16 / (int)sizeof(T);
-    const int nf = W / VW;
-    if (w < nf * VW) return ((int64_t)(w / VW) * B + i) * VW + (w % VW);
-    const int rem = W - nf * VW;
-    return (int64_t)nf * VW * B + i * rem + (w - nf * VW);
+    const int64_t tile = i / kTile;
+    const int lane = (int)(i % kTile);
+    const int nf = WT / VW;
+    const int64_t base = tile * WT * kTile;
+    if (w < nf * VW) return base + ((int64_t)(w / VW) * kTile + lane) * VW + (w % VW);
+    const int rem = WT - nf * VW;
+    return base + (int64_t)nf * VW * kTile + lane * rem + (w - nf * VW);
 }
 
-template <typename T, int W>
-__device__ __forceinline__ void load_rec(const T* __restrict__ base, int64_t B, int64_t i, T (&r)[W])
+// Load words [W0, W0+W) of filter i's WT-word record.  W0 and W are whole quads,
+// except that the load may end with the record's 8-byte tail row (fp32 only).
+template <typename T, int WT, int W0, int W>
+__device__ __forceinline__ void load_rec(const T* __restrict__ base, int64_t i, T (&r)[W])
 {
     using Q = typename Quad<T>::type;
     constexpr int VW = Quad<T>::VW;
-    constexpr int NF = W / VW;
+    constexpr int NFT = WT / VW;       // full quad rows in the record
+    constexpr int NF = W / VW;         // full quad rows in this load
     constexpr int REM = W % VW;
-    const Q* q = reinterpret_cast<const Q*>(base);
+    static_assert(W0 % VW == 0, "loads start on a quad row");
+    static_assert(REM == 0 || (REM == 2 && W0 + W == WT && W0 / VW + NF == NFT), "only the record's own 8-byte tail may be partial");
+    const int64_t tile = i >> 6;
+    const int lane = (int)(i & 63);
+    const T* tb = base + tile * (int64_t)(WT * kTile);
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        Q v = q[(int64_t)k * B + i];
+        Q v = *reinterpret_cast<const Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW);
         unpack_quad(v, &r[k * VW]);
     }
-    if (REM == 2) {  // fp32 only: trailing row of 8-byte halves
-        const float2* h = reinterpret_cast<const float2*>(base + (int64_t)NF * VW * B);
-        float2 v = h[i];
+    if (REM == 2) {
+        float2 v = *reinterpret_cast<const float2*>(tb + NFT * VW * kTile + lane * 2);
         r[NF * VW] = v.x;
         r[NF * VW + 1] = v.y;
     }
-    static_assert(REM == 0 || REM == 2, "record tail must be empty or one 8-byte half");
 }
 
-template <typename T, int W>
-__device__ __forceinline__ void store_rec(T* __restrict__ base, int64_t B, int64_t i, const T (&r)[W])
+template <typename T, int WT, int W0, int W>
+__device__ __forceinline__ void store_rec(T* __restrict__ base, int64_t i, const T (&r)[W])
 {
     using Q = typename Quad<T>::type;
     constexpr int VW = Quad<T>::VW;
     constexpr int NF = W / VW;
-    static_assert(W % VW == 0, "stored records are whole quads");
-    Q* q = reinterpret_cast<Q*>(base);
+    static_assert(W % VW == 0 && W0 % VW == 0, "stored ranges are whole quads");
+    const int64_t tile = i >> 6;
+    const int lane = (int)(i & 63);
+    T* tb = base + tile * (int64_t)(WT * kTile);
 #pragma unroll
-    for (int k = 0; k < NF; ++k) q[(int64_t)k * B + i] = pack_quad(&r[k * VW]);
+    for (int k = 0; k < NF; ++k) *reinterpret_cast<Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW) = pack_quad(&r[k * VW]);
 }
 
 template <typename T, bool PFP>
-__device__ __forceinline__ void load_noise(const DevParams<T>& p, const T* __restrict__ pfp, int64_t B, int64_t i, Noise<T>& nz)
+__device__ __forceinline__ void load_noise(const DevParams<T>& p, const T* __restrict__ pfp, int64_t i, Noise<T>& nz)
 {
     if (PFP) {
         T f[kFW];
-        load_rec<T, kFW>(pfp, B, i, f);
+        load_rec<T, kFW, 0, kFW>(pfp, i, f);
 #pragma unroll
         for (int k = 0; k < 12; ++k) nz.Q[k] = f[k];
 #pragma unroll
@@ -101,21 +131,20 @@ __device__ __forceinline__ void load_noise(const DevParams<T>& p, const T* __res
 // ------------------------------------------------------------- hot kernels
 // Predict tick: reads x16 + P120 + u6, writes x16 + P120 (278 words/filter).
 template <typename T, bool PFP, bool AUX>
-__global__ __launch_bounds__(kBlock) void k_predict(DevParams<T> p, T* __restrict__ xs, T* __restrict__ Ps,
-                                                    const T* __restrict__ us, const T* __restrict__ pfp,
-                                                    T* __restrict__ aux_accel, int64_t B)
+__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, T* __restrict__ st, const T* __restrict__ us,
+                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3];
-    load_rec<T, kUW>(us, B, i, u);
-    load_rec<T, kXW>(xs, B, i, x);
-    load_rec<T, kPW>(Ps, B, i, P);
+    load_rec<T, kUW, 0, kUW>(us, i, u);
+    load_rec<T, kSW, 0, kXW>(st, i, x);
+    load_rec<T, kSW, kXW, kPW>(st, i, P);
     Noise<T> nz;
-    load_noise<T, PFP>(p, pfp, B, i, nz);
+    load_noise<T, PFP>(p, pfp, i, nz);
     ekf_predict<T>(p, nz, x, P, u, accel);
-    store_rec<T, kXW>(xs, B, i, x);
-    store_rec<T, kPW>(Ps, B, i, P);
+    store_rec<T, kSW, 0, kXW>(st, i, x);
+    store_rec<T, kSW, kXW, kPW>(st, i, P);
     if (AUX) {  // side output, AoS [B][3] in the compute dtype
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
@@ -126,20 +155,19 @@ __global__ __launch_bounds__(kBlock) void k_predict(DevParams<T> p, T* __restric
 // predict, then correct where the record's mask word is non-zero.
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
 template <typename T, bool DIRECT, bool PFP, bool AUX>
-__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__ xs, T* __restrict__ Ps,
-                                                 const T* __restrict__ us, const T* __restrict__ zs,
-                                                 const T* __restrict__ pfp, T* __restrict__ aux_accel,
-                                                 T* __restrict__ aux_obs, int64_t B)
+__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__ st, const T* __restrict__ us,
+                                                 const T* __restrict__ zs, const T* __restrict__ pfp,
+                                                 T* __restrict__ aux_accel, T* __restrict__ aux_obs, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], zr[kZW], accel[3];
-    load_rec<T, kUW>(us, B, i, u);
-    load_rec<T, kZW>(zs, B, i, zr);
-    load_rec<T, kXW>(xs, B, i, x);
-    load_rec<T, kPW>(Ps, B, i, P);
+    load_rec<T, kUW, 0, kUW>(us, i, u);
+    load_rec<T, kZW, 0, kZW>(zs, i, zr);
+    load_rec<T, kSW, 0, kXW>(st, i, x);
+    load_rec<T, kSW, kXW, kPW>(st, i, P);
     Noise<T> nz;
-    load_noise<T, PFP>(p, pfp, B, i, nz);
+    load_noise<T, PFP>(p, pfp, i, nz);
     ekf_predict<T>(p, nz, x, P, u, accel);
     T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
     const bool corr = zr[7] != T(0);
@@ -147,8 +175,8 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__
         T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
         ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
     }
-    store_rec<T, kXW>(xs, B, i, x);
-    store_rec<T, kPW>(Ps, B, i, P);
+    store_rec<T, kSW, 0, kXW>(st, i, x);
+    store_rec<T, kSW, kXW, kPW>(st, i, P);
     if (AUX) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
@@ -161,25 +189,24 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__
 
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
 template <typename T, bool DIRECT, bool PFP, bool AUX>
-__global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ xs, T* __restrict__ Ps,
-                                                   const T* __restrict__ zs, const T* __restrict__ pfp,
-                                                   T* __restrict__ aux_obs, int64_t B)
+__global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ st, const T* __restrict__ zs,
+                                                   const T* __restrict__ pfp, T* __restrict__ aux_obs, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T zr[kZW];
-    load_rec<T, kZW>(zs, B, i, zr);
+    load_rec<T, kZW, 0, kZW>(zs, i, zr);
     if (zr[7] == T(0)) return;
     T x[kXW], P[kPW];
-    load_rec<T, kXW>(xs, B, i, x);
-    load_rec<T, kPW>(Ps, B, i, P);
+    load_rec<T, kSW, 0, kXW>(st, i, x);
+    load_rec<T, kSW, kXW, kPW>(st, i, P);
     Noise<T> nz;
-    load_noise<T, PFP>(p, pfp, B, i, nz);
+    load_noise<T, PFP>(p, pfp, i, nz);
     T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
     T obs[7];
     ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
-    store_rec<T, kXW>(xs, B, i, x);
-    store_rec<T, kPW>(Ps, B, i, P);
+    store_rec<T, kSW, 0, kXW>(st, i, x);
+    store_rec<T, kSW, kXW, kPW>(st, i, P);
     if (AUX) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
@@ -187,43 +214,44 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
 }
 
 // ------------------------------------------------ layout conversion kernels
-// Host-facing AoS fp64 <-> device quad rows, one chunk [i0, i0+n) of the batch
-// per launch (the AoS side is a staging buffer holding only that chunk).
+// Host-facing AoS fp64 <-> device tiles, one chunk [i0, i0+n) of the batch per
+// launch (the AoS side is a staging buffer holding only that chunk).  W words
+// of the host row go to words [w0, w0+W) of the WT-word device record.
 // Not on the hot path.
 template <typename T>
-__global__ void k_pack_off(const double* __restrict__ aos, int stride, int W, T* __restrict__ dst, int64_t B, int64_t i0, int64_t n)
+__global__ void k_pack_off(const double* __restrict__ aos, int stride, int W, T* __restrict__ dst, int WT, int w0, int64_t i0, int64_t n)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
-    for (int w = 0; w < W; ++w) dst[word_off<T>(w, i0 + li, B, W)] = (T)aos[li * stride + w];
+    for (int w = 0; w < W; ++w) dst[word_off<T>(w0 + w, i0 + li, WT)] = (T)aos[li * stride + w];
 }
 template <typename T>
-__global__ void k_unpack_off(const T* __restrict__ src, int stride, int W, double* __restrict__ aos, int64_t B, int64_t i0, int64_t n)
+__global__ void k_unpack_off(const T* __restrict__ src, int stride, int W, double* __restrict__ aos, int WT, int w0, int64_t i0, int64_t n)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
-    for (int w = 0; w < W; ++w) aos[li * stride + w] = (double)src[word_off<T>(w, i0 + li, B, W)];
+    for (int w = 0; w < W; ++w) aos[li * stride + w] = (double)src[word_off<T>(w0 + w, i0 + li, WT)];
 }
 // z (7) + mask -> 8-word record; z == nullptr writes an identity pose, mask == nullptr means "all".
 template <typename T>
-__global__ void k_pack_z_off(const double* __restrict__ z, const uint8_t* __restrict__ mask, T* __restrict__ dst, int64_t B, int64_t i0, int64_t n)
+__global__ void k_pack_z_off(const double* __restrict__ z, const uint8_t* __restrict__ mask, T* __restrict__ dst, int64_t i0, int64_t n)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
-    for (int w = 0; w < 7; ++w) dst[word_off<T>(w, i0 + li, B, kZW)] = z ? (T)z[li * 7 + w] : (w == 6 ? T(1) : T(0));
-    dst[word_off<T>(7, i0 + li, B, kZW)] = (mask == nullptr || mask[li]) ? T(1) : T(0);
+    for (int w = 0; w < 7; ++w) dst[word_off<T>(w, i0 + li, kZW)] = z ? (T)z[li * 7 + w] : (w == 6 ? T(1) : T(0));
+    dst[word_off<T>(7, i0 + li, kZW)] = (mask == nullptr || mask[li]) ? T(1) : T(0);
 }
 template <typename T>
-__global__ void k_unpack_z_off(const T* __restrict__ src, double* __restrict__ z, uint8_t* __restrict__ mask, int64_t B, int64_t i0, int64_t n)
+__global__ void k_unpack_z_off(const T* __restrict__ src, double* __restrict__ z, uint8_t* __restrict__ mask, int64_t i0, int64_t n)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
-    for (int w = 0; w < 7; ++w) z[li * 7 + w] = (double)src[word_off<T>(w, i0 + li, B, kZW)];
-    mask[li] = src[word_off<T>(7, i0 + li, B, kZW)] != T(0) ? 1 : 0;
+    for (int w = 0; w < 7; ++w) z[li * 7 + w] = (double)src[word_off<T>(w, i0 + li, kZW)];
+    mask[li] = src[word_off<T>(7, i0 + li, kZW)] != T(0) ? 1 : 0;
 }
-// Full n x n row-major covariance -> packed symmetric part (P + P^T)/2.
+// Full n x n row-major covariance -> packed symmetric part (P + P^T)/2 of the state record.
 template <typename T>
-__global__ void k_pack_P_off(const double* __restrict__ Pf, int n, T* __restrict__ dst, int64_t B, int64_t i0, int64_t m)
+__global__ void k_pack_P_off(const double* __restrict__ Pf, int n, T* __restrict__ st, int64_t i0, int64_t m)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= m) return;
@@ -231,29 +259,29 @@ __global__ void k_pack_P_off(const double* __restrict__ Pf, int n, T* __restrict
     for (int a = 0; a < 15; ++a)
         for (int b = a; b < 15; ++b) {
             double v = (a < n && b < n) ? 0.5 * (Pi[a * n + b] + Pi[b * n + a]) : 0.0;
-            dst[word_off<T>(sidx(a, b), i0 + li, B, kPW)] = (T)v;
+            st[word_off<T>(kXW + sidx(a, b), i0 + li, kSW)] = (T)v;
         }
 }
 template <typename T>
-__global__ void k_unpack_P_off(const T* __restrict__ src, int n, double* __restrict__ Pf, int64_t B, int64_t i0, int64_t m)
+__global__ void k_unpack_P_off(const T* __restrict__ st, int n, double* __restrict__ Pf, int64_t i0, int64_t m)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= m) return;
     double* Pi = Pf + li * n * n;
     for (int a = 0; a < n; ++a)
-        for (int b = 0; b < n; ++b) Pi[a * n + b] = (double)src[word_off<T>(sidx(a, b), i0 + li, B, kPW)];
+        for (int b = 0; b < n; ++b) Pi[a * n + b] = (double)st[word_off<T>(kXW + sidx(a, b), i0 + li, kSW)];
 }
 
 // initialize_state, EKF.cpp:305-344, one filter per lane.
 template <typename T>
-__global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__ xs, T* __restrict__ Ps, T cov0, T cov1,
-                       T cov2, T cov3, T cov4, int reinit_bias, int64_t B)
+__global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__ st, T cov0, T cov1, T cov2, T cov3, T cov4,
+                       int reinit_bias, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T zr[kZW], x[kXW], P[kPW];
-    load_rec<T, kZW>(zs, B, i, zr);
-    load_rec<T, kXW>(xs, B, i, x);
+    load_rec<T, kZW, 0, kZW>(zs, i, zr);
+    load_rec<T, kSW, 0, kXW>(st, i, x);
     T qct[4] = {zr[3], zr[4], zr[5], zr[6]}, t[4], qn[4], C[9], pv[3];
     quat_mul(p.q_vc, qct, t);                       // EKF.cpp:310
     qn[0] = -t[0]; qn[1] = -t[1]; qn[2] = -t[2]; qn[3] = t[3];
@@ -276,44 +304,42 @@ __global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__
         P[sidx(k, k)] = cov0; P[sidx(3 + k, 3 + k)] = cov1; P[sidx(6 + k, 6 + k)] = cov2;
         P[sidx(9 + k, 9 + k)] = cov3; P[sidx(12 + k, 12 + k)] = cov4;
     }
-    store_rec<T, kXW>(xs, B, i, x);
-    store_rec<T, kPW>(Ps, B, i, P);
+    store_rec<T, kSW, 0, kXW>(st, i, x);
+    store_rec<T, kSW, kXW, kPW>(st, i, P);
 }
 
-// What the node publishes after a tick (NODE.cpp:192-220), AoS fp64.
+// What the node publishes after a tick (NODE.cpp:192-220), AoS fp64, one chunk.
 template <typename T>
-__global__ void k_report_off(DevParams<T> p, const T* __restrict__ xs, const T* __restrict__ Ps, const T* __restrict__ pfp,
-                             double* __restrict__ pose, double* __restrict__ pose_cov, double* __restrict__ vel,
-                             double* __restrict__ bias, int64_t B, int64_t i0, int64_t n)
+__global__ void k_report_off(DevParams<T> p, const T* __restrict__ st, const T* __restrict__ pfp, double* __restrict__ pose,
+                             double* __restrict__ pose_cov, double* __restrict__ vel, double* __restrict__ bias, int64_t i0, int64_t n)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= n) return;
     const int64_t i = i0 + li;
-    auto X = [&](int w) { return (double)xs[word_off<T>(w, i, B, kXW)]; };
+    auto X = [&](int w) { return (double)st[word_off<T>(w, i, kSW)]; };
     for (int k = 0; k < 3; ++k) pose[li * 7 + k] = X(k);
     for (int k = 0; k < 4; ++k) pose[li * 7 + 3 + k] = X(6 + k);
     {  // rows/cols {0-2, 6-8}, row-major (NODE.cpp:203-210)
         const int sel[6] = {0, 1, 2, 6, 7, 8};
         for (int a = 0; a < 6; ++a)
-            for (int b = 0; b < 6; ++b) pose_cov[li * 36 + a * 6 + b] = (double)Ps[word_off<T>(sidx(sel[a], sel[b]), i, B, kPW)];
+            for (int b = 0; b < 6; ++b) pose_cov[li * 36 + a * 6 + b] = X(kXW + sidx(sel[a], sel[b]));
     }
     for (int k = 0; k < 3; ++k) vel[li * 3 + k] = X(3 + k);
     for (int k = 0; k < 3; ++k) {  // ab_nom + ab_static, wb_nom + wb_static (NODE.cpp:215-220)
-        double as = pfp ? (double)pfp[word_off<T>(12 + k, i, B, kFW)] : (double)p.ab_static[k];
-        double ws = pfp ? (double)pfp[word_off<T>(15 + k, i, B, kFW)] : (double)p.wb_static[k];
+        double as = pfp ? (double)pfp[word_off<T>(12 + k, i, kFW)] : (double)p.ab_static[k];
+        double ws = pfp ? (double)pfp[word_off<T>(15 + k, i, kFW)] : (double)p.wb_static[k];
         bias[li * 6 + k] = X(10 + k) + as;
         bias[li * 6 + 3 + k] = X(13 + k) + ws;
     }
 }
 
 template <typename T>
-__global__ void k_count_nonfinite(const T* __restrict__ xs, const T* __restrict__ Ps, unsigned long long* __restrict__ out, int64_t B)
+__global__ void k_count_nonfinite(const T* __restrict__ st, unsigned long long* __restrict__ out, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     bool bad = false;
-    for (int w = 0; w < kXW; ++w) bad |= !isfinite((double)xs[word_off<T>(w, i, B, kXW)]);
-    for (int w = 0; w < kPW; ++w) bad |= !isfinite((double)Ps[word_off<T>(w, i, B, kPW)]);
+    for (int w = 0; w < kSW; ++w) bad |= !isfinite((double)st[word_off<T>(w, i, kSW)]);
     if (bad) atomicAdd(out, 1ULL);
 }
 

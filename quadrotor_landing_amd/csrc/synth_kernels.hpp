@@ -135,12 +135,12 @@ __global__ void k_synth(SynthArgs a, const int32_t* __restrict__ slot, T* __rest
         }
     }
     if (pfp) {
-        for (int k = 0; k < 12; ++k) pfp[word_off<T>(k, i, a.B, kFW)] = (T)Qf[k];
+        for (int k = 0; k < 12; ++k) pfp[word_off<T>(k, i, kFW)] = (T)Qf[k];
         for (int k = 0; k < 3; ++k) {
-            pfp[word_off<T>(12 + k, i, a.B, kFW)] = (T)abs_[k];
-            pfp[word_off<T>(15 + k, i, a.B, kFW)] = (T)wbs_[k];
+            pfp[word_off<T>(12 + k, i, kFW)] = (T)abs_[k];
+            pfp[word_off<T>(15 + k, i, kFW)] = (T)wbs_[k];
         }
-        for (int k = 0; k < 6; ++k) pfp[word_off<T>(18 + k, i, a.B, kFW)] = (T)Rf[k];
+        for (int k = 0; k < 6; ++k) pfp[word_off<T>(18 + k, i, kFW)] = (T)Rf[k];
     }
 
     double r[3];
@@ -148,8 +148,8 @@ __global__ void k_synth(SynthArgs a, const int32_t* __restrict__ slot, T* __rest
     {   // seeding pose at time 0
         double z[7];
         synth_measure(a, gi, kTickSeedMeas, r, s.q, a.R, z);
-        for (int k = 0; k < 7; ++k) z0[word_off<T>(k, i, a.B, kZW)] = (T)z[k];
-        z0[word_off<T>(7, i, a.B, kZW)] = T(1);
+        for (int k = 0; k < 7; ++k) z0[word_off<T>(k, i, kZW)] = (T)z[k];
+        z0[word_off<T>(7, i, kZW)] = T(1);
     }
     for (int64_t t = 0; t < a.T; ++t) {
         const double tt = (double)t * a.dT;
@@ -165,8 +165,8 @@ __global__ void k_synth(SynthArgs a, const int32_t* __restrict__ slot, T* __rest
             double am = (C[k] * acc[0] + C[3 + k] * acc[1] + C[6 + k] * acc[2]) + s.ab[k] + abs_[k] +
                         a.imu_scale * sqrt(a.Q[k]) * rng_normal(a.seed, gi, (uint64_t)t, k);
             double wm = w[k] + s.wb[k] + wbs_[k] + a.imu_scale * sqrt(a.Q[3 + k]) * rng_normal(a.seed, gi, (uint64_t)t, 3 + k);
-            ut[word_off<T>(k, i, a.B, kUW)] = (T)am;
-            ut[word_off<T>(3 + k, i, a.B, kUW)] = (T)wm;
+            ut[word_off<T>(k, i, kUW)] = (T)am;
+            ut[word_off<T>(3 + k, i, kUW)] = (T)wm;
         }
         // truth advances one tick: exact exponential map with the rate held over the tick
         double dw[3] = {a.dT * w[0], a.dT * w[1], a.dT * w[2]}, qe[4], qn[4];
@@ -180,8 +180,8 @@ __global__ void k_synth(SynthArgs a, const int32_t* __restrict__ slot, T* __rest
             double z[7];
             synth_measure(a, gi, (uint64_t)t, r, s.q, a.R, z);
             T* zt = zs + (int64_t)sl * a.pitch_z_words;
-            for (int k = 0; k < 7; ++k) zt[word_off<T>(k, i, a.B, kZW)] = (T)z[k];
-            zt[word_off<T>(7, i, a.B, kZW)] = T(1);
+            for (int k = 0; k < 7; ++k) zt[word_off<T>(k, i, kZW)] = (T)z[k];
+            zt[word_off<T>(7, i, kZW)] = T(1);
         }
     }
     for (int k = 0; k < 3; ++k) truth[i * 7 + k] = r[k];
@@ -199,10 +199,10 @@ __global__ void k_rmse(const T* __restrict__ xs, const double* __restrict__ trut
     if (i < B) {
         double q[4], qt_c[4], dq[4], th[3];
         for (int k = 0; k < 3; ++k) {
-            double d = (double)xs[word_off<T>(k, i, B, kXW)] - truth[i * 7 + k];
+            double d = (double)xs[word_off<T>(k, i, kSW)] - truth[i * 7 + k];
             er += d * d;
         }
-        for (int k = 0; k < 4; ++k) q[k] = (double)xs[word_off<T>(6 + k, i, B, kXW)];
+        for (int k = 0; k < 4; ++k) q[k] = (double)xs[word_off<T>(6 + k, i, kSW)];
         qt_c[0] = -truth[i * 7 + 3]; qt_c[1] = -truth[i * 7 + 4]; qt_c[2] = -truth[i * 7 + 5]; qt_c[3] = truth[i * 7 + 6];
         quat_mul<double>(qt_c, q, dq);
         if (dq[3] < 0) { dq[0] = -dq[0]; dq[1] = -dq[1]; dq[2] = -dq[2]; dq[3] = -dq[3]; }
