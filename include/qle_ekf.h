@@ -158,6 +158,24 @@ int qle_update(qle_batch *h, const double *z, const uint8_t *mask);
  * z/mask may be NULL for a predict-only tick. */
 int qle_step(qle_batch *h, const double *u, const double *z, const uint8_t *mask);
 
+/* ---- the decision logic of filter_update on the device ----------------------
+ * With gating enabled, the mask of qle_step / qle_filter_update / the mask word
+ * of a sequence slot means "measurement_ready" (EKF.hpp:125), and the engine
+ * decides per filter as filter_update does (EKF.cpp:147-186):
+ *   consume = ready && (!limit_measurement_freq || upds_since_correction+1 >= upd_per_meas)
+ *   perform = consume && (!corner_margin_enbl || a tag of the bundle projects inside the image margins)
+ * and maintains upds_since_correction / performed_correction (EKF.cpp:292-301).
+ * Refused while multirate_ekf is set (the replay of EKF.cpp:196-236 is not implemented). */
+int qle_enable_gating(qle_batch *h, int32_t on);
+/* RelativePoseEKF::filter_update(t), single-rate branch (EKF.cpp:127-193,238-303):
+ * u = latest IMU sample per filter [batch][6] (NODE.cpp:144-151), z = latest tag
+ * pose [batch][7] or NULL, measurement_ready = [batch] or NULL (= all ready). */
+int qle_filter_update(qle_batch *h, const double *u, const double *z, const uint8_t *measurement_ready);
+/* After a tick: performed_correction (EKF.hpp:126), whether the pending measurement
+ * was consumed (the reference clears measurement_ready, EKF.cpp:152) and
+ * upds_since_correction (EKF.hpp:128).  Any pointer may be NULL. */
+int qle_get_tick_flags(qle_batch *h, uint8_t *performed_correction, uint8_t *consumed, int32_t *upds_since_correction);
+
 /* ---- device-resident input sequences -------------------------------------- */
 /* n_ticks of IMU input for the handle's batch; tick_has_meas[t] != 0 reserves
  * a tag-pose slot (z + per-filter mask) for tick t. */

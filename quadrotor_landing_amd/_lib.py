@@ -86,6 +86,9 @@ SYMBOLS = {
     "qle_predict": (C.c_int, [_vp, _pd]),
     "qle_update": (C.c_int, [_vp, _pd, _pu8]),
     "qle_step": (C.c_int, [_vp, _pd, _pd, _pu8]),
+    "qle_enable_gating": (C.c_int, [_vp, _i32]),
+    "qle_filter_update": (C.c_int, [_vp, _pd, _pd, _pu8]),
+    "qle_get_tick_flags": (C.c_int, [_vp, _pu8, _pu8, C.POINTER(_i32)]),
     "qle_inputs_create": (C.c_int, [_vp, _i64, _pu8, C.POINTER(_vp)]),
     "qle_inputs_destroy": (C.c_int, [_vp]),
     "qle_inputs_upload_tick": (C.c_int, [_vp, _i64, _pd, _pd, _pu8]),

@@ -156,6 +156,11 @@ struct qle_batch {
     uint8_t* stage_mask = nullptr;
     unsigned long long* counter = nullptr;
     bool state_set = false;
+    // device-side measurement gating (EKF.cpp:147-186)
+    bool gating = false;
+    int32_t* last_corr = nullptr;  // [B] index of each filter's last correcting tick, -1 = never
+    uint8_t* flags = nullptr;      // [B] bit0 performed_correction, bit1 measurement consumed (last measurement tick)
+    int64_t tick = 0;              // filter_update ticks executed so far
 };
 
 struct qle_inputs {
@@ -222,7 +227,7 @@ extern "C" int qle_destroy(qle_batch* h)
     if (!h) return QLE_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->st, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter};
+    void* bufs[] = {h->st, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -456,40 +461,55 @@ static int launch_predict(qle_batch* h, const void* u)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *acc = (T*)h->aux_accel;
+    T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on) {
-        if (h->aux) hipLaunchKernelGGL((k_predict<T, true, true>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-        else hipLaunchKernelGGL((k_predict<T, true, false>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-    } else {
-        if (h->aux) hipLaunchKernelGGL((k_predict<T, false, true>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-        else hipLaunchKernelGGL((k_predict<T, false, false>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-    }
+    if (h->pfp_on) hipLaunchKernelGGL((k_predict<T, true>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+    else hipLaunchKernelGGL((k_predict<T, false>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
 
-template <typename T, bool DIRECT>
-static int launch_step_d(qle_batch* h, const void* u, const void* z)
+static GateParams make_gate(const qle_batch* h)
+{
+    GateParams g;
+    std::memset(&g, 0, sizeof(g));
+    g.limit = h->pub.limit_measurement_freq;
+    g.upd_per_meas = h->der.upd_per_meas;
+    g.corner_enbl = h->pub.corner_margin_enbl;
+    g.n_tags = h->pub.n_tags;
+    g.tick = (int32_t)h->tick;
+    for (int i = 0; i < 9; ++i) g.K[i] = h->pub.camera_K[i];
+    const double m = h->pub.tag_in_view_margin;
+    g.x_lo = h->pub.camera_width * m;  g.x_hi = h->pub.camera_width * (1 - m);    // EKF.cpp:175-178
+    g.y_lo = h->pub.camera_height * m; g.y_hi = h->pub.camera_height * (1 - m);
+    for (int i = 0; i < QLE_MAX_TAGS; ++i) {
+        g.hw[i] = h->pub.tag_widths[i] / 2;
+        g.px[i] = h->pub.tag_positions[3 * i];
+        g.py[i] = h->pub.tag_positions[3 * i + 1];
+    }
+    return g;
+}
+
+template <typename T, bool DIRECT, bool GATE>
+static int launch_step_dg(qle_batch* h, const void* u, const void* z)
 {
     const DevParams<T>& p = dev<T>(h);
+    const GateParams gp = make_gate(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *acc = (T*)h->aux_accel, *obs = (T*)h->aux_obs;
+    T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on) {
-        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, true, true>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
-        else hipLaunchKernelGGL((k_step<T, DIRECT, true, false>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
-    } else {
-        if (h->aux) hipLaunchKernelGGL((k_step<T, DIRECT, false, true>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
-        else hipLaunchKernelGGL((k_step<T, DIRECT, false, false>), g, b, 0, h->stream, p, st, (const T*)u, (const T*)z, pfp, acc, obs, h->B);
-    }
+    if (h->pfp_on)
+        hipLaunchKernelGGL((k_step<T, DIRECT, true, GATE>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B);
+    else
+        hipLaunchKernelGGL((k_step<T, DIRECT, false, GATE>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
 template <typename T>
 static int launch_step(qle_batch* h, const void* u, const void* z)
 {
-    return h->pub.direct_orien_method ? launch_step_d<T, true>(h, u, z) : launch_step_d<T, false>(h, u, z);
+    if (h->pub.direct_orien_method) return h->gating ? launch_step_dg<T, true, true>(h, u, z) : launch_step_dg<T, true, false>(h, u, z);
+    return h->gating ? launch_step_dg<T, false, true>(h, u, z) : launch_step_dg<T, false, false>(h, u, z);
 }
 
 template <typename T, bool DIRECT>
@@ -497,15 +517,10 @@ static int launch_update_d(qle_batch* h, const void* z)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *obs = (T*)h->aux_obs;
+    T *st = (T*)h->st, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on) {
-        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, true, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-        else hipLaunchKernelGGL((k_update<T, DIRECT, true, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-    } else {
-        if (h->aux) hipLaunchKernelGGL((k_update<T, DIRECT, false, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-        else hipLaunchKernelGGL((k_update<T, DIRECT, false, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-    }
+    if (h->pfp_on) hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
+    else hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
@@ -543,9 +558,54 @@ extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const ui
     QLE_TRY(need_state(h));
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
-    if (!z) return BY_DTYPE(h, launch_predict, h, h->tick_u);
-    QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
-    return BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z);
+    if (!z) {
+        QLE_TRY(BY_DTYPE(h, launch_predict, h, h->tick_u));
+    } else {
+        QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
+        QLE_TRY(BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z));
+    }
+    h->tick++;
+    return QLE_OK;
+}
+
+// ---- device-side gating: the full single-rate filter_update decision logic ----
+extern "C" int qle_enable_gating(qle_batch* h, int32_t on)
+{
+    QLE_TRY(check_handle(h));
+    if (on && h->pub.multirate_ekf) return fail(QLE_ERR_INVALID, "multirate_ekf is set: the delayed-measurement replay (EKF.cpp:196-236) is not implemented in this engine yet");
+    if (on && !h->last_corr) {
+        HIP_TRY(hipMalloc((void**)&h->last_corr, sizeof(int32_t) * (size_t)h->Bp));
+        HIP_TRY(hipMalloc((void**)&h->flags, (size_t)h->Bp));
+        HIP_TRY(hipMemsetAsync(h->last_corr, 0xFF, sizeof(int32_t) * (size_t)h->Bp, h->stream));  // -1
+        HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));
+    }
+    h->gating = on != 0;
+    return QLE_OK;
+}
+
+extern "C" int qle_filter_update(qle_batch* h, const double* u, const double* z, const uint8_t* measurement_ready)
+{
+    QLE_TRY(check_handle(h));
+    if (!h->gating) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
+    if (z == nullptr && h->flags) HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));  // performed_correction = false
+    return qle_step(h, u, z, measurement_ready);
+}
+
+extern "C" int qle_get_tick_flags(qle_batch* h, uint8_t* performed_correction, uint8_t* consumed, int32_t* upds_since_correction)
+{
+    QLE_TRY(check_handle(h));
+    if (!h->last_corr) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
+    std::vector<uint8_t> f((size_t)h->B);
+    std::vector<int32_t> lc((size_t)h->B);
+    HIP_TRY(hipMemcpyAsync(f.data(), h->flags, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipMemcpyAsync(lc.data(), h->last_corr, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    for (int64_t i = 0; i < h->B; ++i) {
+        if (performed_correction) performed_correction[i] = f[(size_t)i] & 1;
+        if (consumed) consumed[i] = (f[(size_t)i] >> 1) & 1;
+        if (upds_since_correction) upds_since_correction[i] = (int32_t)(h->tick - 1 - lc[(size_t)i]);  // EKF.cpp:292-299
+    }
+    return QLE_OK;
 }
 
 template <typename T>
@@ -720,6 +780,7 @@ extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n
         const int32_t s = in->slot[(size_t)t];
         if (s < 0) QLE_TRY(BY_DTYPE(h, launch_predict, h, u_at(in, t)));
         else QLE_TRY(BY_DTYPE(h, launch_step, h, u_at(in, t), z_at(in, s)));
+        h->tick++;
     }
     return QLE_OK;
 }

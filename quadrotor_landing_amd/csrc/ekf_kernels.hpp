@@ -128,9 +128,52 @@ __device__ __forceinline__ void load_noise(const DevParams<T>& p, const T* __res
     }
 }
 
+// --------------------------------------------------------- measurement gate
+// Decision logic of filter_update, EKF.cpp:147-186, per filter on the device:
+//   consume  = measurement_ready && (!limit_measurement_freq || upds_since_correction + 1 >= upd_per_meas)
+//   perform  = consume && (!corner_margin_enbl || some tag of the bundle projects inside the image margins)
+// upds_since_correction is kept implicitly: last_corr[i] is the index of the filter's last correcting
+// tick (-1 = never), so upds_since_correction before tick n is n - last_corr[i] - 1 and predict-only
+// ticks never touch the array.  The projection runs in fp64 whatever the compute dtype, so the
+// discrete decision matches the fp64 reference for the same (dtype-rounded) tag pose.
+struct GateParams {
+    int32_t limit;              // limit_measurement_freq (EKF.hpp:75)
+    int32_t upd_per_meas;       // EKF.cpp:91
+    int32_t corner_enbl;        // corner_margin_enbl (EKF.hpp:76)
+    int32_t n_tags;             // EKF.hpp:117
+    int32_t tick;               // index of this tick
+    double K[9];                // camera_K row-major
+    double x_lo, x_hi, y_lo, y_hi;  // camera_width*margin, camera_width*(1-margin), same for height (EKF.cpp:175-178)
+    double hw[16], px[16], py[16];  // tag_widths/2, tag_positions x,y (EKF.cpp:163-164)
+};
+
+__device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
+{
+    double q[4] = {z[3], z[4], z[5], z[6]}, C[9];
+    quat_to_rot<double>(q, C);  // T_ct = Translation(r_c_tc) * q_ct, EKF.cpp:154
+    for (int t = 0; t < g.n_tags; ++t) {
+        const double hw = g.hw[t];
+        const double cx[4] = {hw + g.px[t], -hw + g.px[t], -hw + g.px[t], hw + g.px[t]};
+        const double cy[4] = {hw + g.py[t], hw + g.py[t], -hw + g.py[t], -hw + g.py[t]};
+        double mnx = 0, mny = 0, mxx = 0, mxy = 0;
+        for (int k = 0; k < 4; ++k) {
+            double pc[3];
+            for (int r = 0; r < 3; ++r) pc[r] = C[3 * r] * cx[k] + C[3 * r + 1] * cy[k] + C[3 * r + 2] * 0.0 + z[r];
+            const double iz = 1.0 / pc[2];                                   // EKF.cpp:168
+            const double nx = pc[0] * iz, ny = pc[1] * iz, nz = pc[2] * iz;  // EKF.cpp:169
+            const double u = g.K[0] * nx + g.K[1] * ny + g.K[2] * nz;        // EKF.cpp:170
+            const double v = g.K[3] * nx + g.K[4] * ny + g.K[5] * nz;
+            if (k == 0) { mnx = mxx = u; mny = mxy = v; }
+            else { mnx = fmin(mnx, u); mxx = fmax(mxx, u); mny = fmin(mny, v); mxy = fmax(mxy, v); }
+        }
+        if (mnx > g.x_lo && mny > g.y_lo && mxx < g.x_hi && mxy < g.y_hi) return true;  // EKF.cpp:175-180
+    }
+    return false;
+}
+
 // ------------------------------------------------------------- hot kernels
 // Predict tick: reads x16 + P120 + u6, writes x16 + P120 (278 words/filter).
-template <typename T, bool PFP, bool AUX>
+template <typename T, bool PFP>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, T* __restrict__ st, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B)
 {
@@ -145,7 +188,7 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
     ekf_predict<T>(p, nz, x, P, u, accel);
     store_rec<T, kSW, 0, kXW>(st, i, x);
     store_rec<T, kSW, kXW, kPW>(st, i, P);
-    if (AUX) {  // side output, AoS [B][3] in the compute dtype
+    if (aux_accel) {  // optional side output (wave-uniform), AoS [B][3] in the compute dtype
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
     }
@@ -154,10 +197,11 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
 // Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290):
 // predict, then correct where the record's mask word is non-zero.
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
-template <typename T, bool DIRECT, bool PFP, bool AUX>
-__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__ st, const T* __restrict__ us,
+template <typename T, bool DIRECT, bool PFP, bool GATE>
+__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, T* __restrict__ st, const T* __restrict__ us,
                                                  const T* __restrict__ zs, const T* __restrict__ pfp,
-                                                 T* __restrict__ aux_accel, T* __restrict__ aux_obs, int64_t B)
+                                                 T* __restrict__ aux_accel, T* __restrict__ aux_obs,
+                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
@@ -166,18 +210,29 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
     load_rec<T, kSW, 0, kXW>(st, i, x);
     load_rec<T, kSW, kXW, kPW>(st, i, P);
+    bool corr = zr[7] != T(0);
+    if (GATE) {  // the mask word means "measurement_ready"; decide here (EKF.cpp:147-186)
+        const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
+        bool ok = consume;
+        if (consume && gp.corner_enbl) {
+            const double zd[7] = {(double)zr[0], (double)zr[1], (double)zr[2], (double)zr[3], (double)zr[4], (double)zr[5], (double)zr[6]};
+            ok = corner_gate(gp, zd);
+        }
+        corr = ok;
+        if (ok) last_corr[i] = gp.tick;
+        flags[i] = (uint8_t)((ok ? 1 : 0) | (consume ? 2 : 0));
+    }
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
     ekf_predict<T>(p, nz, x, P, u, accel);
     T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
-    const bool corr = zr[7] != T(0);
     if (corr) {
         T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
         ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
     }
     store_rec<T, kSW, 0, kXW>(st, i, x);
     store_rec<T, kSW, kXW, kPW>(st, i, P);
-    if (AUX) {
+    if (aux_accel) {  // optional side outputs (wave-uniform)
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
         if (corr) {
@@ -188,7 +243,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, T* __restrict__
 }
 
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
-template <typename T, bool DIRECT, bool PFP, bool AUX>
+template <typename T, bool DIRECT, bool PFP>
 __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ st, const T* __restrict__ zs,
                                                    const T* __restrict__ pfp, T* __restrict__ aux_obs, int64_t B)
 {
@@ -207,7 +262,7 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
     ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
     store_rec<T, kSW, 0, kXW>(st, i, x);
     store_rec<T, kSW, kXW, kPW>(st, i, P);
-    if (AUX) {
+    if (aux_obs) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
     }

@@ -166,6 +166,22 @@ class BatchedRelativePoseEKF:
         zz = None if z is None else _f64(z, (self.batch, 7))
         check(lib().qle_step(self._h, _dp(_f64(u, (self.batch, 6))), _dp(zz), None if m is None else m.ctypes.data_as(_pu8)))
 
+    # ---- filter_update with the decision logic on the device (relative_pose_EKF.cpp:147-186)
+    def enable_gating(self, on=True):
+        check(lib().qle_enable_gating(self._h, int(bool(on))))
+
+    def filter_update(self, u, z=None, measurement_ready=None):
+        """One filter_update tick: rate limit + corner gate + predict (+ correct) per filter."""
+        m = _u8(measurement_ready, (self.batch,))
+        zz = None if z is None else _f64(z, (self.batch, 7))
+        check(lib().qle_filter_update(self._h, _dp(_f64(u, (self.batch, 6))), _dp(zz), None if m is None else m.ctypes.data_as(_pu8)))
+
+    def tick_flags(self):
+        """(performed_correction, consumed, upds_since_correction) after the last tick."""
+        pc = np.zeros(self.batch, np.uint8); co = np.zeros(self.batch, np.uint8); up = np.zeros(self.batch, np.int32)
+        check(lib().qle_get_tick_flags(self._h, pc.ctypes.data_as(_pu8), co.ctypes.data_as(_pu8), up.ctypes.data_as(C.POINTER(C.c_int32))))
+        return pc, co, up
+
     # ---- reference-shaped value-in / value-out calls
     def prediction_step(self, x_km1, P_km1, u):
         """prediction_step(x_km1, P_km1, u) -> (x_check, P_check, pose_accel)   (relative_pose_EKF.cpp:346-415)."""

@@ -377,3 +377,85 @@ def test_cfg3_full_size_properties_fp32():
     relF = np.linalg.norm(Pg[idx] - Pr, axis=(1, 2)) / np.linalg.norm(Pr, axis=(1, 2))
     assert relF.max() < 5e-3, relF.max()
     ekf.close()
+
+
+# ------------------------------------------- filter_update decision logic
+HW_TAGS = dict(
+    n_tags=13, tag_in_view_margin=0.0,
+    tag_widths=[0.08382] + [0.16764] * 4 + [0.33528] * 4 + [0.16764] * 4,
+    tag_positions=[0, 0, 0, 0, 0.1571625, 0, 0.1571625, 0, 0, 0, -0.1571625, 0, -0.1571625, 0, 0, -0.244475, 0.244475, 0,
+                   0.244475, 0.244475, 0, 0.244475, -0.244475, 0, -0.244475, -0.244475, 0, 0, 0.314325, 0, 0.314325, 0, 0,
+                   0, -0.314325, 0, -0.314325, 0, 0],
+    camera_K=[437.3412312213781, 0, 328.5442810236917, 0, 438.0867474272743, 239.2536470406629, 0, 0, 1],
+    camera_width=640, camera_height=480)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("cfg", [dict(limit_measurement_freq=1, measurement_freq=30.0, corner_margin_enbl=1),
+                                 dict(limit_measurement_freq=0, corner_margin_enbl=1, **HW_TAGS),
+                                 dict(limit_measurement_freq=1, measurement_freq=15.0, corner_margin_enbl=0)])
+def test_filter_update_gating_matches_reference_logic(cfg, dtype):
+    """Device-side rate limit + corner gate + counters vs the oracle's full filter_update (EKF.cpp:127-303)."""
+    kw = dict(update_freq=100.0, direct_orien_method=1, **cfg)
+    po, pq = both(**kw)
+    rng = np.random.default_rng(33)
+    B, T = 96, 40
+    x, P = rand_states(rng, B, 15, cov_scale=0.2)
+    x[:, 0:3] = rng.uniform([-0.4, -0.4, 0.8], [0.4, 0.4, 2.5], size=(B, 3))
+    x[:, 6:10] = np.array([0, 0, 0, 1.0])  # level, so that the tag is roughly in front of the camera
+    if dtype == "f32":
+        x = x.astype(np.float32).astype(np.float64); P = P.astype(np.float32).astype(np.float64)
+    ekf = qla.BatchedRelativePoseEKF(B, dtype, params=pq)
+    ekf.enable_gating(True)
+    ekf.set_state(x, P)
+    filt = []
+    for i in range(B):
+        f = oracle.Filter(po)
+        for k in range(3):
+            f.f.r_nom[k] = x[i, k]; f.f.v_nom[k] = x[i, 3 + k]; f.f.ab_nom[k] = x[i, 10 + k]; f.f.wb_nom[k] = x[i, 13 + k]
+        for k in range(4):
+            f.f.q_nom[k] = x[i, 6 + k]
+        for k in range(225):
+            f.f.cov_pert[k] = P[i].reshape(-1)[k]
+        f.f.state_initialized = 1
+        filt.append(f)
+    pending = np.zeros(B, np.uint8)
+    zlast = np.zeros((B, 7)); zlast[:, 6] = 1
+    n_perf = n_rej = 0
+    for t in range(T):
+        u = rand_imu(rng, B) * np.array([0.05, 0.05, 1, 0.2, 0.2, 0.2])
+        new = rng.uniform(size=B) < 0.5
+        xs = ekf.get_state()[0]
+        znew = meas_near(rng, po, xs, ang=0.3, pos=0.05)
+        znew[:, 0:2] += rng.choice([0.0, 0.0, 1.5], size=(B, 1)) * rng.normal(size=(B, 2))  # some tags out of view
+        if dtype == "f32":
+            u = u.astype(np.float32).astype(np.float64); znew = znew.astype(np.float32).astype(np.float64)
+        zlast[new] = znew[new]
+        pending |= new.astype(np.uint8)
+        for i in range(B):
+            filt[i].set_imu(u[i, :3], u[i, 3:])
+            if new[i]:
+                filt[i].set_apriltag(zlast[i, :3], zlast[i, 3:], 0.01 * t)
+            filt[i].filter_update(0.01 * t)
+        ekf.filter_update(u, zlast if pending.any() else None, pending if pending.any() else None)
+        perf, cons, upds = ekf.tick_flags()
+        ref_perf = np.array([f.f.performed_correction for f in filt], np.uint8)
+        ref_ready = np.array([f.f.measurement_ready for f in filt], np.uint8)
+        ref_upds = np.array([f.f.upds_since_correction for f in filt], np.int32)
+        pending &= (1 - cons)
+        np.testing.assert_array_equal(perf, ref_perf)
+        np.testing.assert_array_equal(pending, ref_ready)   # consumed <=> the reference cleared measurement_ready
+        np.testing.assert_array_equal(upds, ref_upds)
+        n_perf += int(perf.sum()); n_rej += int((cons & (1 - perf)).sum())
+    assert n_perf > B and (n_rej > 0 or not cfg["corner_margin_enbl"])
+    xg, Pg = ekf.get_state()
+    xr = np.stack([f.x() for f in filt]); Pr = np.stack([f.P() for f in filt])
+    if dtype == "f64":
+        assert_state_close(xg, Pg, xr, Pr, 1e-10, 1e-12, 1e-10)
+    else:
+        assert_state_close(xg, Pg, xr, Pr, 5e-4, 5e-4, 5e-4)
+    # multirate is refused loudly rather than silently run single-rate
+    ekf2 = qla.BatchedRelativePoseEKF(4, dtype, multirate_ekf=1)
+    with pytest.raises(qla.QleError):
+        ekf2.enable_gating(True)
+    ekf.close(); ekf2.close()
