@@ -164,13 +164,30 @@ int qle_step(qle_batch *h, const double *u, const double *z, const uint8_t *mask
  * decides per filter as filter_update does (EKF.cpp:147-186):
  *   consume = ready && (!limit_measurement_freq || upds_since_correction+1 >= upd_per_meas)
  *   perform = consume && (!corner_margin_enbl || a tag of the bundle projects inside the image margins)
- * and maintains upds_since_correction / performed_correction (EKF.cpp:292-301).
- * Refused while multirate_ekf is set (the replay of EKF.cpp:196-236 is not implemented). */
+ * and maintains upds_since_correction / performed_correction (EKF.cpp:292-301). */
 int qle_enable_gating(qle_batch *h, int32_t on);
 /* RelativePoseEKF::filter_update(t), single-rate branch (EKF.cpp:127-193,238-303):
  * u = latest IMU sample per filter [batch][6] (NODE.cpp:144-151), z = latest tag
  * pose [batch][7] or NULL, measurement_ready = [batch] or NULL (= all ready). */
 int qle_filter_update(qle_batch *h, const double *u, const double *z, const uint8_t *measurement_ready);
+/* The same with the time stamps the multirate EKF needs for dynamic_meas_delay
+ * (EKF.cpp:199): t_curr = the tick's time, apriltag_time = [batch] header stamp of each
+ * filter's latest tag pose (EKF.hpp:43, NODE.cpp:167).
+ *
+ * multirate_ekf = true (EKF.cpp:196-236, 251-264): every filter keeps a history of
+ * (x, u, P) per tick in HBM; a correction is applied to the entry the measurement
+ * belongs to, step = max(int(delay/dT_nom + 0.5), 1) ticks back, and the predictions
+ * since are replayed from the stored IMU samples.  All tick entry points (qle_step,
+ * qle_filter_update*, qle_run) follow that branch while the parameter is set;
+ * qle_set_state / qle_initialize_state / bare qle_predict / qle_update restart the
+ * history with a single entry (EKF.cpp:337-339). */
+int qle_filter_update_stamped(qle_batch *h, const double *u, const double *z, const uint8_t *measurement_ready,
+                              double t_curr, const double *apriltag_time);
+/* measurement_delay_curr of each filter's last correction (EKF.hpp:86, EKF.cpp:199). */
+int qle_get_measurement_delay(qle_batch *h, double *measurement_delay_curr);
+/* Measurement age used for dynamic_meas_delay when no per-filter stamps are given
+ * (qle_step, qle_run): default = measurement_delay. */
+int qle_set_uniform_measurement_age(qle_batch *h, double seconds);
 /* After a tick: performed_correction (EKF.hpp:126), whether the pending measurement
  * was consumed (the reference clears measurement_ready, EKF.cpp:152) and
  * upds_since_correction (EKF.hpp:128).  Any pointer may be NULL. */
@@ -200,7 +217,8 @@ typedef struct qle_synth_cfg {
     double meas_noise_scale;             /* 1 = N(0,R) on tag poses */
     double imu_noise_scale;              /* 1 = N(0,Q_a), N(0,Q_w) on IMU */
     int32_t perturb_filter_params;       /* cfg 5: also fill per-filter Q scale and static biases */
-    int32_t _pad0;
+    int32_t meas_delay_ticks;            /* multirate runs: a tag pose delivered at tick t shows the pose after tick
+                                            t - meas_delay_ticks (0 = no latency, single-rate) */
 } qle_synth_cfg;
 int qle_synth_cfg_default(qle_synth_cfg *c);
 /* Fill `in` with a generated sequence and seed the filters from the first

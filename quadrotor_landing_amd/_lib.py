@@ -51,7 +51,7 @@ class QleSynthCfg(C.Structure):
     _fields_ = [
         ("seed", _u64), ("filter_offset", _i64),
         ("ab_true_sigma", _d), ("wb_true_sigma", _d), ("meas_noise_scale", _d), ("imu_noise_scale", _d),
-        ("perturb_filter_params", _i32), ("_pad0", _i32),
+        ("perturb_filter_params", _i32), ("meas_delay_ticks", _i32),
     ]
 
 
@@ -88,6 +88,9 @@ SYMBOLS = {
     "qle_step": (C.c_int, [_vp, _pd, _pd, _pu8]),
     "qle_enable_gating": (C.c_int, [_vp, _i32]),
     "qle_filter_update": (C.c_int, [_vp, _pd, _pd, _pu8]),
+    "qle_filter_update_stamped": (C.c_int, [_vp, _pd, _pd, _pu8, _d, _pd]),
+    "qle_get_measurement_delay": (C.c_int, [_vp, _pd]),
+    "qle_set_uniform_measurement_age": (C.c_int, [_vp, _d]),
     "qle_get_tick_flags": (C.c_int, [_vp, _pu8, _pu8, C.POINTER(_i32)]),
     "qle_inputs_create": (C.c_int, [_vp, _i64, _pu8, C.POINTER(_vp)]),
     "qle_inputs_destroy": (C.c_int, [_vp]),

@@ -161,6 +161,16 @@ struct qle_batch {
     int32_t* last_corr = nullptr;  // [B] index of each filter's last correcting tick, -1 = never
     uint8_t* flags = nullptr;      // [B] bit0 performed_correction, bit1 measurement consumed (last measurement tick)
     int64_t tick = 0;              // filter_update ticks executed so far
+    // multirate EKF (EKF.cpp:196-236, 251-264)
+    bool mr = false;               // pub.multirate_ekf
+    bool hist_dirty = true;        // state was overwritten: restart the history at the next tick
+    int32_t mr_C = 0;              // ring capacity in slots
+    void* ring = nullptr;          // [C][tiles][144 words]
+    int32_t* hist_len = nullptr;   // [B]
+    double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
+    double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
+    double t_curr = 0.0, uniform_age = 0.0;
+    bool have_stamps = false;
 };
 
 struct qle_inputs {
@@ -219,6 +229,27 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
     h->der = d;
     h->pf = make_dev<float>(*p, d);
     h->pd = make_dev<double>(*p, d);
+    // multirate history ring: C = largest reachable step delay + 1 (EKF.cpp:199-201)
+    h->mr = p->multirate_ekf != 0;
+    if (h->mr) {
+        int32_t step_max = d.measurement_step_delay;
+        if (p->dynamic_meas_delay) step_max = std::max((int32_t)(p->measurement_delay_max / d.dT_nom + 0.5), 1);
+        const int32_t C = step_max + 1;
+        if (C > h->mr_C) {
+            if (h->ring) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->ring)); h->ring = nullptr; }
+            hipError_t e = hipMalloc(&h->ring, (size_t)C * kHWpad * (size_t)h->Bp * h->wsz);
+            if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "hipMalloc of the multirate history ring (%d slots x %lld filters): %s", C, (long long)h->Bp, hipGetErrorString(e));
+            h->mr_C = C;
+        }
+        if (!h->hist_len) {
+            HIP_TRY(hipMalloc((void**)&h->hist_len, sizeof(int32_t) * (size_t)h->Bp));
+            HIP_TRY(hipMalloc((void**)&h->stamp, sizeof(double) * (size_t)h->Bp));
+            HIP_TRY(hipMalloc((void**)&h->delay_cur, sizeof(double) * (size_t)h->Bp));
+            HIP_TRY(hipMemsetAsync(h->delay_cur, 0, sizeof(double) * (size_t)h->Bp, h->stream));
+        }
+        h->hist_dirty = true;
+        h->uniform_age = p->measurement_delay;
+    }
     return QLE_OK;
 }
 
@@ -227,7 +258,8 @@ extern "C" int qle_destroy(qle_batch* h)
     if (!h) return QLE_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->st, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags};
+    void* bufs[] = {h->st, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->ring, h->hist_len, h->stamp,
+                    h->delay_cur};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -264,13 +296,13 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     int rc = QLE_OK;
     auto bail = [&](int code) { qle_destroy(h); return code; };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipSetDevice(%d) failed", device));
+    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipStreamCreate failed"));
     if ((rc = qle_set_params(h, p)) != QLE_OK) return bail(rc);
 #define ALLOC(ptr, bytes)                                                                               \
     do {                                                                                                \
         hipError_t ea_ = hipMalloc((void**)&(ptr), (bytes));                                            \
         if (ea_ != hipSuccess) return bail(fail(QLE_ERR_NOMEM, "hipMalloc(%zu B) for %s: %s", (size_t)(bytes), #ptr, hipGetErrorString(ea_))); \
     } while (0)
-    if (hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipStreamCreate failed"));
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipEventCreate failed"));
     const size_t B = (size_t)h->Bp, w = h->wsz;
     ALLOC(h->st, kSW * B * w);
@@ -401,6 +433,7 @@ extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
     QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, h->st, kSW, 0));
     QLE_TRY(BY_DTYPE(h, pack_P, h, P, h->st));
     h->state_set = true;
+    h->hist_dirty = true;
     return QLE_OK;
 }
 extern "C" int qle_get_state(qle_batch* h, double* x, double* P)
@@ -505,9 +538,53 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
+static MrParams make_mr(const qle_batch* h, bool has_meas)
+{
+    MrParams m;
+    std::memset(&m, 0, sizeof(m));
+    m.C = h->mr_C;
+    m.tick = (int32_t)h->tick;
+    m.fixed_step = h->der.measurement_step_delay;
+    m.dynamic = h->pub.dynamic_meas_delay;
+    m.gate = h->gating ? 1 : 0;
+    m.has_meas = has_meas ? 1 : 0;
+    m.slot_words = (int64_t)kHWpad * h->Bp;
+    m.dT = h->der.dT_nom;
+    m.offset = h->pub.dyn_measurement_delay_offset;
+    m.delay_max = h->pub.measurement_delay_max;
+    m.t_curr = h->t_curr;
+    m.uniform_age = h->uniform_age;
+    return m;
+}
+
+// One multirate tick (predict-only when z == nullptr).
+template <typename T>
+static int launch_step_mr(qle_batch* h, const void* u, const void* z)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const GateParams gp = make_gate(h);
+    const MrParams m = make_mr(h, z != nullptr);
+    if (h->hist_dirty) {  // restart the history with the single entry {x, 0, P} (EKF.cpp:337-339)
+        hipLaunchKernelGGL((k_hist_reset<T>), grid_for(h, 256), dim3(256), 0, h->stream, m, (const T*)h->st, (T*)h->ring, h->hist_len, h->B);
+        HIP_TRY(hipGetLastError());
+        h->hist_dirty = false;
+    }
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
+    const T* pfp = (const T*)h->pfp;
+    const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
+#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, st, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_len, h->last_corr, h->flags, h->delay_cur, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
+    else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
+#undef QLE_MR_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+
 template <typename T>
 static int launch_step(qle_batch* h, const void* u, const void* z)
 {
+    if (h->mr) return launch_step_mr<T>(h, u, z);
     if (h->pub.direct_orien_method) return h->gating ? launch_step_dg<T, true, true>(h, u, z) : launch_step_dg<T, true, false>(h, u, z);
     return h->gating ? launch_step_dg<T, false, true>(h, u, z) : launch_step_dg<T, false, false>(h, u, z);
 }
@@ -542,6 +619,7 @@ extern "C" int qle_predict(qle_batch* h, const double* u)
     QLE_TRY(need_state(h));
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
+    h->hist_dirty = true;  // a bare prediction_step is not a filter tick: the multirate history restarts
     return BY_DTYPE(h, launch_predict, h, h->tick_u);
 }
 extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)
@@ -550,6 +628,7 @@ extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)
     QLE_TRY(need_state(h));
     if (!z) return fail(QLE_ERR_INVALID, "z is null");
     QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
+    h->hist_dirty = true;
     return BY_DTYPE(h, launch_update, h, h->tick_z);
 }
 extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const uint8_t* mask)
@@ -559,7 +638,8 @@ extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const ui
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     if (!z) {
-        QLE_TRY(BY_DTYPE(h, launch_predict, h, h->tick_u));
+        if (h->mr) QLE_TRY(BY_DTYPE(h, launch_step_mr, h, h->tick_u, (const void*)nullptr));
+        else QLE_TRY(BY_DTYPE(h, launch_predict, h, h->tick_u));
     } else {
         QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
         QLE_TRY(BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z));
@@ -572,7 +652,6 @@ extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const ui
 extern "C" int qle_enable_gating(qle_batch* h, int32_t on)
 {
     QLE_TRY(check_handle(h));
-    if (on && h->pub.multirate_ekf) return fail(QLE_ERR_INVALID, "multirate_ekf is set: the delayed-measurement replay (EKF.cpp:196-236) is not implemented in this engine yet");
     if (on && !h->last_corr) {
         HIP_TRY(hipMalloc((void**)&h->last_corr, sizeof(int32_t) * (size_t)h->Bp));
         HIP_TRY(hipMalloc((void**)&h->flags, (size_t)h->Bp));
@@ -588,7 +667,44 @@ extern "C" int qle_filter_update(qle_batch* h, const double* u, const double* z,
     QLE_TRY(check_handle(h));
     if (!h->gating) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
     if (z == nullptr && h->flags) HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));  // performed_correction = false
+    h->have_stamps = false;
     return qle_step(h, u, z, measurement_ready);
+}
+
+extern "C" int qle_filter_update_stamped(qle_batch* h, const double* u, const double* z, const uint8_t* measurement_ready, double t_curr,
+                                         const double* apriltag_time)
+{
+    QLE_TRY(check_handle(h));
+    if (!h->gating) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
+    if (z == nullptr && h->flags) HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));
+    h->t_curr = t_curr;
+    h->have_stamps = false;
+    if (h->mr && apriltag_time && z) {
+        HIP_TRY(hipMemcpyAsync(h->stamp, apriltag_time, sizeof(double) * (size_t)h->B, hipMemcpyHostToDevice, h->stream));
+        HIP_TRY(hipStreamSynchronize(h->stream));
+        h->have_stamps = true;
+    }
+    return qle_step(h, u, z, measurement_ready);
+}
+
+extern "C" int qle_get_measurement_delay(qle_batch* h, double* measurement_delay_curr)
+{
+    QLE_TRY(check_handle(h));
+    if (!measurement_delay_curr) return fail(QLE_ERR_INVALID, "output is null");
+    if (!h->mr || !h->pub.dynamic_meas_delay) {  // fixed delay (EKF.cpp:199)
+        for (int64_t i = 0; i < h->B; ++i) measurement_delay_curr[i] = h->pub.measurement_delay;
+        return QLE_OK;
+    }
+    HIP_TRY(hipMemcpyAsync(measurement_delay_curr, h->delay_cur, sizeof(double) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    return QLE_OK;
+}
+
+extern "C" int qle_set_uniform_measurement_age(qle_batch* h, double seconds)
+{
+    QLE_TRY(check_handle(h));
+    h->uniform_age = seconds;
+    return QLE_OK;
 }
 
 extern "C" int qle_get_tick_flags(qle_batch* h, uint8_t* performed_correction, uint8_t* consumed, int32_t* upds_since_correction)
@@ -624,6 +740,7 @@ extern "C" int qle_initialize_state(qle_batch* h, const double* z, int32_t reini
     QLE_TRY(BY_DTYPE(h, pack_z, h, z, (const uint8_t*)nullptr, h->tick_z));
     QLE_TRY(BY_DTYPE(h, seed_t, h, reinit_bias));
     h->state_set = true;
+    h->hist_dirty = true;
     return QLE_OK;
 }
 
@@ -778,8 +895,12 @@ extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n
     for (int64_t k = 0; k < n; ++k) {
         const int64_t t = (t0 + k) % in->T;
         const int32_t s = in->slot[(size_t)t];
-        if (s < 0) QLE_TRY(BY_DTYPE(h, launch_predict, h, u_at(in, t)));
-        else QLE_TRY(BY_DTYPE(h, launch_step, h, u_at(in, t), z_at(in, s)));
+        if (s < 0) {
+            if (h->mr) QLE_TRY(BY_DTYPE(h, launch_step_mr, h, u_at(in, t), (const void*)nullptr));
+            else QLE_TRY(BY_DTYPE(h, launch_predict, h, u_at(in, t)));
+        } else {
+            QLE_TRY(BY_DTYPE(h, launch_step, h, u_at(in, t), z_at(in, s)));
+        }
         h->tick++;
     }
     return QLE_OK;
@@ -809,6 +930,7 @@ static int synth_t(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
     a.meas_scale = c->meas_noise_scale;
     a.imu_scale = c->imu_noise_scale;
     a.perturb = c->perturb_filter_params;
+    a.meas_delay_ticks = c->meas_delay_ticks < 0 ? 0 : (c->meas_delay_ticks > kSynthMaxDelay ? kSynthMaxDelay : c->meas_delay_ticks);
     a.dT = h->der.dT_nom;
     for (int i = 0; i < 12; ++i) a.Q[i] = h->der.Q[i];
     for (int i = 0; i < 6; ++i) a.R[i] = h->der.R[i];
@@ -849,6 +971,7 @@ extern "C" int qle_synth_generate(qle_batch* h, qle_inputs* in, const qle_synth_
     // seed every filter from the generator's first (pre-sequence) tag pose, left in tick_z
     QLE_TRY(BY_DTYPE(h, seed_t, h, 1));
     h->state_set = true;
+    h->hist_dirty = true;
     return QLE_OK;
 }
 

@@ -1,0 +1,205 @@
+// ekf_driver.cpp -- ROS-free replacement of the reference's rel_pose_EKF_node executable
+// (quad_state_estimation/src/relative_pose_EKF_main.cpp + relative_pose_EKF_node.cpp).
+//
+// Where the node loads ROS parameters (NODE.cpp:11-136), subscribes to IMU / AprilTag topics
+// (NODE.cpp:39-40) and runs filter_update on a timer (NODE.cpp:50,178-182), this driver
+//   1. reads the same keys from one of the reference's EKF YAML files,
+//   2. creates a batch of filters on one MI355X through the C-ABI,
+//   3. generates a seeded synthetic IMU + tag-pose sequence on the device (qle_synth_generate),
+//   4. runs the tick loop with the decision logic on the device (rate limit + corner gate),
+//   5. prints what the node publishes for filter 0 (NODE.cpp:192-220) and the RMSE vs the truth.
+//
+//   ekf_driver --config relative_pose_EKF_rotors.yaml --batch 65536 --ticks 1000 [--dtype f32|f64]
+//              [--device 0] [--seed N] [--update-freq HZ] [--measurement-freq HZ] [--corner-gate 0|1] [--multirate 0|1]
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "../../include/qle_ekf.h"
+
+namespace {
+
+// Minimal parser for the subset of YAML the reference's parameter files use:
+// `key: scalar`, `key: [a, b, ...]` (lists may span lines), `#` comments.
+std::map<std::string, std::vector<std::string>> parse_yaml(const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(2); }
+    std::map<std::string, std::vector<std::string>> out;
+    std::string line, key, acc;
+    bool in_list = false;
+    auto strip = [](std::string s) {
+        size_t a = s.find_first_not_of(" \t\r\n\"'"), b = s.find_last_not_of(" \t\r\n\"'");
+        return a == std::string::npos ? std::string() : s.substr(a, b - a + 1);
+    };
+    auto finish_list = [&]() {
+        std::vector<std::string> v;
+        std::stringstream ss(acc);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) { tok = strip(tok); if (!tok.empty()) v.push_back(tok); }
+        out[key] = v;
+        in_list = false; acc.clear();
+    };
+    while (std::getline(in, line)) {
+        size_t h = line.find('#');
+        if (h != std::string::npos) line = line.substr(0, h);
+        if (strip(line).empty()) continue;
+        if (in_list) {
+            size_t e = line.find(']');
+            acc += " " + (e == std::string::npos ? line : line.substr(0, e));
+            if (e != std::string::npos) finish_list();
+            continue;
+        }
+        size_t c = line.find(':');
+        if (c == std::string::npos) continue;
+        key = strip(line.substr(0, c));
+        std::string val = strip(line.substr(c + 1));
+        if (!val.empty() && val[0] == '[') {
+            size_t e = val.find(']');
+            acc = e == std::string::npos ? val.substr(1) : val.substr(1, e - 1);
+            in_list = true;
+            if (e != std::string::npos) finish_list();
+        } else {
+            out[key] = {val};
+        }
+    }
+    return out;
+}
+
+bool as_bool(const std::string& s) { return s == "True" || s == "true" || s == "1" || s == "yes"; }
+
+void check(int rc, const char* what)
+{
+    if (rc != QLE_OK) { std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, qle_last_error()); std::exit(1); }
+}
+
+}  // namespace
+
+int main(int argc, char** argv)
+{
+    std::string config;
+    int64_t batch = 4096, ticks = 1000;
+    int dtype = QLE_F32, device = 0;
+    uint64_t seed = 0xE4F00001ULL;
+    double update_freq = 0, measurement_freq = 0;
+    int corner_gate = -1, multirate = -1;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        auto next = [&]() { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return std::string(argv[++i]); };
+        if (a == "--config") config = next();
+        else if (a == "--batch") batch = std::atoll(next().c_str());
+        else if (a == "--ticks") ticks = std::atoll(next().c_str());
+        else if (a == "--dtype") dtype = next() == "f64" ? QLE_F64 : QLE_F32;
+        else if (a == "--device") device = std::atoi(next().c_str());
+        else if (a == "--seed") seed = std::strtoull(next().c_str(), nullptr, 0);
+        else if (a == "--update-freq") update_freq = std::atof(next().c_str());
+        else if (a == "--measurement-freq") measurement_freq = std::atof(next().c_str());
+        else if (a == "--corner-gate") corner_gate = std::atoi(next().c_str());
+        else if (a == "--multirate") multirate = std::atoi(next().c_str());
+        else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
+    }
+
+    qle_params p;
+    check(qle_params_default(&p), "qle_params_default");
+    if (!config.empty()) {
+        auto y = parse_yaml(config);
+        auto num = [&](const char* k, double& dst) { if (y.count(k)) dst = std::atof(y[k][0].c_str()); };
+        auto flag = [&](const char* k, int32_t& dst) { if (y.count(k)) dst = as_bool(y[k][0]) ? 1 : 0; };
+        auto vec = [&](const char* k, double* dst, size_t cap, bool required) {
+            if (!y.count(k)) { if (required) { std::fprintf(stderr, "%s: required key %s missing (NODE.cpp reads it with getParam, no default)\n", config.c_str(), k); std::exit(2); } return (size_t)0; }
+            if (y[k].size() > cap) { std::fprintf(stderr, "%s has %zu values, capacity %zu\n", k, y[k].size(), cap); std::exit(2); }
+            for (size_t j = 0; j < y[k].size(); ++j) dst[j] = std::atof(y[k][j].c_str());
+            return y[k].size();
+        };
+        num("update_freq", p.update_freq); num("measurement_freq", p.measurement_freq);          // NODE.cpp:31-32
+        num("measurement_delay", p.measurement_delay); num("measurement_delay_max", p.measurement_delay_max);
+        num("dyn_measurement_delay_offset", p.dyn_measurement_delay_offset);                      // NODE.cpp:33-35
+        flag("limit_measurement_freq", p.limit_measurement_freq);                                 // NODE.cpp:36
+        flag("est_bias", p.est_bias); flag("corner_margin_enbl", p.corner_margin_enbl);          // NODE.cpp:60-61
+        flag("direct_orien_method", p.direct_orien_method); flag("multirate_ekf", p.multirate_ekf);
+        flag("dynamic_meas_delay", p.dynamic_meas_delay);                                         // NODE.cpp:62-64
+        vec("Q_a_diag", p.Q_a, 3, true); vec("Q_w_diag", p.Q_w, 3, true); vec("Q_ab_diag", p.Q_ab, 3, true); vec("Q_wb_diag", p.Q_wb, 3, true);
+        vec("R_r_diag", p.R_r, 3, true); vec("R_ang_diag", p.R_ang, 3, true);                     // NODE.cpp:71-87
+        num("r_cov_init", p.r_cov_init); num("v_cov_init", p.v_cov_init); num("ang_cov_init", p.ang_cov_init);
+        num("ab_cov_init", p.ab_cov_init); num("wb_cov_init", p.wb_cov_init);                     // NODE.cpp:89-93
+        vec("accel_bias_static", p.ab_static, 3, true); vec("gyro_bias_static", p.wb_static, 3, true);  // NODE.cpp:98-101
+        vec("r_v_cv", p.r_v_cv, 3, true); vec("q_vc", p.q_vc, 4, true);                            // NODE.cpp:106-109
+        double cw = p.camera_width, ch = p.camera_height, nt = p.n_tags;
+        num("camera_width", cw); num("camera_height", ch); num("n_tags", nt);                      // NODE.cpp:112-113,119
+        p.camera_width = (int32_t)std::lround(cw); p.camera_height = (int32_t)std::lround(ch); p.n_tags = (int32_t)std::lround(nt);
+        vec("camera_K", p.camera_K, 9, true);                                                      // NODE.cpp:115-117
+        num("tag_in_view_margin", p.tag_in_view_margin);                                           // NODE.cpp:120
+        vec("tag_widths", p.tag_widths, QLE_MAX_TAGS, true); vec("tag_positions", p.tag_positions, 3 * QLE_MAX_TAGS, true);
+    }
+    if (update_freq > 0) p.update_freq = update_freq;
+    if (measurement_freq > 0) p.measurement_freq = measurement_freq;
+    if (corner_gate >= 0) p.corner_margin_enbl = corner_gate;
+    if (multirate >= 0) p.multirate_ekf = multirate;
+    qle_derived d;
+    check(qle_params_derive(&p, &d), "qle_params_derive");
+
+    qle_batch* h = nullptr;
+    check(qle_create(&h, batch, dtype, device, &p), "qle_create");
+    check(qle_enable_gating(h, 1), "qle_enable_gating");
+    // a tag pose arrives every upd_per_meas ticks (the detector runs at measurement_freq)
+    std::vector<uint8_t> has((size_t)ticks, 0);
+    for (int64_t t = d.upd_per_meas - 1; t < ticks; t += d.upd_per_meas) has[(size_t)t] = 1;
+    qle_inputs* in = nullptr;
+    check(qle_inputs_create(h, ticks, has.data(), &in), "qle_inputs_create");
+    qle_synth_cfg sc;
+    check(qle_synth_cfg_default(&sc), "qle_synth_cfg_default");
+    sc.seed = seed;
+    if (p.multirate_ekf) {
+        // camera latency of the synthetic source = the configured measurement_delay (EKF.cpp:93,199):
+        // a tag pose delivered at tick t shows the pose `measurement_step_delay` ticks back.
+        sc.meas_delay_ticks = d.measurement_step_delay;
+        check(qle_set_uniform_measurement_age(h, p.dynamic_meas_delay ? d.measurement_step_delay * d.dT_nom - p.dyn_measurement_delay_offset
+                                                                       : p.measurement_delay), "qle_set_uniform_measurement_age");
+    }
+    check(qle_synth_generate(h, in, &sc), "qle_synth_generate");
+
+    check(qle_synchronize(h), "qle_synchronize");
+    auto t0 = std::chrono::steady_clock::now();
+    check(qle_timer_begin(h), "qle_timer_begin");
+    check(qle_run(h, in, 0, ticks), "qle_run");
+    float ms = 0;
+    check(qle_timer_end(h, &ms), "qle_timer_end");
+    double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+
+    std::vector<double> pose((size_t)batch * 7), cov((size_t)batch * 36), vel((size_t)batch * 3), bias((size_t)batch * 6);
+    check(qle_get_report(h, pose.data(), cov.data(), vel.data(), bias.data()), "qle_get_report");
+    std::vector<uint8_t> perf((size_t)batch), cons((size_t)batch);
+    std::vector<int32_t> upds((size_t)batch);
+    check(qle_get_tick_flags(h, perf.data(), cons.data(), upds.data()), "qle_get_tick_flags");
+    double rm[3];
+    check(qle_synth_rmse(h, in, rm), "qle_synth_rmse");
+    int64_t bad = 0;
+    check(qle_count_nonfinite(h, &bad), "qle_count_nonfinite");
+
+    std::printf("%s\n", qle_version());
+    std::printf("params: update_freq %.1f Hz, measurement_freq %.1f Hz (every %d ticks), num_states %d, direct_orien_method %d, limit %d, corner gate %d, n_tags %d, multirate %d (step delay %d)\n",
+                p.update_freq, p.measurement_freq, d.upd_per_meas, d.num_states, p.direct_orien_method, p.limit_measurement_freq, p.corner_margin_enbl, p.n_tags,
+                p.multirate_ekf, d.measurement_step_delay);
+    std::printf("batch %lld x %lld ticks (%s): %.3f ms device, %.3f ms wall -> %.3e ticks/s\n", (long long)batch, (long long)ticks,
+                dtype == QLE_F32 ? "fp32" : "fp64", ms, wall * 1e3, (double)batch * ticks / (ms * 1e-3));
+    std::printf("filter 0: rel_pose position (%.4f, %.4f, %.4f) orientation xyzw (%.4f, %.4f, %.4f, %.4f)\n", pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
+    std::printf("filter 0: velocity (%.4f, %.4f, %.4f)  IMU bias+static accel (%.4f, %.4f, %.4f) gyro (%.5f, %.5f, %.5f)\n", vel[0], vel[1], vel[2], bias[0], bias[1],
+                bias[2], bias[3], bias[4], bias[5]);
+    std::printf("filter 0: pose covariance diag (%.3e, %.3e, %.3e, %.3e, %.3e, %.3e)  upds_since_correction %d\n", cov[0], cov[7], cov[14], cov[21], cov[28], cov[35], upds[0]);
+    int64_t tracked = 0;
+    for (int64_t i = 0; i < batch; ++i) tracked += upds[(size_t)i] < 2 * d.upd_per_meas ? 1 : 0;
+    std::printf("filters corrected within the last %d ticks: %lld of %lld (the corner gate, EKF.cpp:156-186, rejects tags outside the image margins)\n",
+                2 * d.upd_per_meas, (long long)tracked, (long long)batch);
+    std::printf("RMSE vs synthetic truth over %.0f filters: position %.4f m, attitude %.4f rad; non-finite filters: %lld\n", rm[2], std::sqrt(rm[0] / rm[2]),
+                std::sqrt(rm[1] / rm[2]), (long long)bad);
+    qle_inputs_destroy(in);
+    qle_destroy(h);
+    return bad == 0 ? 0 : 3;
+}

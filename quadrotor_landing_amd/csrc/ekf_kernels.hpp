@@ -242,6 +242,147 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
     }
 }
 
+// ------------------------------------------------------------ multirate EKF
+// filter_update with multirate_ekf = true (EKF.cpp:196-236, 251-264): a tag pose that was taken
+// `step` ticks ago is fused into the state the filter held THEN, and the predictions since are
+// replayed with the stored IMU samples.
+//
+// History layout: the reference keeps per-filter vectors x_hist/u_hist/P_hist (EKF.hpp:62-64) whose
+// entries belong to consecutive ticks.  Here entry "tick n" of every filter lives in ring slot
+// n % C of one HBM array [C][tiles][142 words] (x16, P120 packed, u6), so filters with equal
+// delays read the same slot and stay coalesced; per filter only hist_len is kept.  The index the
+// reference computes, ind = max(len - step, 0) (EKF.cpp:201), never reaches further back than
+// step_max = the largest step delay the parameters allow, so a ring of C >= step_max slots
+// reproduces the unbounded vectors exactly (entries beyond it are unreachable).
+constexpr int kHW = kSW + kUW;  // history record: state record + IMU sample
+constexpr int kHWpad = 144;     // padded to whole quads for fp32 and fp64
+
+struct MrParams {
+    int32_t C;            // ring capacity (slots)
+    int32_t tick;         // index n of this tick; the newest history entry is tick n-1
+    int32_t fixed_step;   // measurement_step_delay (EKF.cpp:93) when !dynamic
+    int32_t dynamic;      // dynamic_meas_delay (EKF.hpp:79)
+    int32_t gate;         // 1: mask word = measurement_ready, decide on device; 0: mask word = perform
+    int32_t has_meas;     // 0: predict-only tick (no tag record to read)
+    int64_t slot_words;   // words per ring slot
+    double dT, offset, delay_max, t_curr, uniform_age;  // EKF.cpp:199-200
+};
+
+template <typename T>
+__device__ __forceinline__ T* ring_slot(T* ring, const MrParams& m, int32_t tick)
+{
+    int32_t s = tick % m.C;
+    if (s < 0) s += m.C;
+    return ring + (int64_t)s * m.slot_words;
+}
+
+template <typename T, bool DIRECT, bool PFP>
+__global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* __restrict__ st, T* __restrict__ ring,
+                                                    const T* __restrict__ us, const T* __restrict__ zs, const T* __restrict__ pfp,
+                                                    const double* __restrict__ stamp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
+                                                    int32_t* __restrict__ hist_len, int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags,
+                                                    double* __restrict__ delay_out, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    T x[kXW], P[kPW], u[kUW], accel[3];
+    T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
+    load_rec<T, kUW, 0, kUW>(us, i, u);
+    Noise<T> nz;
+    load_noise<T, PFP>(p, pfp, i, nz);
+    int32_t len = hist_len[i];
+    bool corr = false;
+    T z[7];
+    if (m.has_meas) {
+        T zr[kZW];
+        load_rec<T, kZW, 0, kZW>(zs, i, zr);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) z[k] = zr[k];
+        corr = zr[7] != T(0);
+        if (m.gate) {  // EKF.cpp:147-186
+            const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
+            bool ok = consume;
+            if (consume && gp.corner_enbl) {
+                const double zd[7] = {(double)zr[0], (double)zr[1], (double)zr[2], (double)zr[3], (double)zr[4], (double)zr[5], (double)zr[6]};
+                ok = corner_gate(gp, zd);
+            }
+            corr = ok;
+            if (ok) last_corr[i] = gp.tick;
+            flags[i] = (uint8_t)((ok ? 1 : 0) | (consume ? 2 : 0));
+        }
+    }
+    if (corr) {
+        // EKF.cpp:199-201: delay -> step delay -> index of the entry the measurement belongs to
+        int32_t step = m.fixed_step;
+        if (m.dynamic) {
+            const double age = stamp ? (m.t_curr - stamp[i]) : m.uniform_age;
+            const double dcur = fmin(age + m.offset, m.delay_max);
+            if (delay_out) delay_out[i] = dcur;
+            step = (int32_t)(dcur / m.dT + 0.5);
+            if (step < 1) step = 1;
+        }
+        int32_t ind = len - step;
+        if (ind < 0) ind = 0;
+        const int32_t tick_m = (m.tick - 1) - (len - 1) + ind;
+        T* sm = ring_slot(ring, m, tick_m);
+        load_rec<T, kHWpad, 0, kXW>(sm, i, x);
+        load_rec<T, kHWpad, kXW, kPW>(sm, i, P);
+        ekf_update<T, DIRECT>(p, nz, x, P, z, obs);           // EKF.cpp:209
+        store_rec<T, kHWpad, 0, kXW>(sm, i, x);               // EKF.cpp:210-211
+        store_rec<T, kHWpad, kXW, kPW>(sm, i, P);
+        len -= ind;                                           // EKF.cpp:214-219
+        for (int32_t k = 1; k < len; ++k) {                   // EKF.cpp:222-226
+            T* sk = ring_slot(ring, m, tick_m + k);
+            T uk[8], foo[3];
+            load_rec<T, kHWpad, kSW, 8>(sk, i, uk);
+            const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
+            ekf_predict<T>(p, nz, x, P, u6, foo);
+            store_rec<T, kHWpad, 0, kXW>(sk, i, x);
+            store_rec<T, kHWpad, kXW, kPW>(sk, i, P);
+        }
+    } else {
+        load_rec<T, kSW, 0, kXW>(st, i, x);                   // nominal state == newest history entry
+        load_rec<T, kSW, kXW, kPW>(st, i, P);
+    }
+    ekf_predict<T>(p, nz, x, P, u, accel);                    // EKF.cpp:249
+    store_rec<T, kSW, 0, kXW>(st, i, x);                      // EKF.cpp:258-263
+    store_rec<T, kSW, kXW, kPW>(st, i, P);
+    {   // EKF.cpp:254-256: append (x_check, u, P_check)
+        T* sn = ring_slot(ring, m, m.tick);
+        store_rec<T, kHWpad, 0, kXW>(sn, i, x);
+        store_rec<T, kHWpad, kXW, kPW>(sn, i, P);
+        const T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+        store_rec<T, kHWpad, kSW, 8>(sn, i, uk);
+        len += 1;
+        if (len > m.C) len = m.C;  // the dropped entry is unreachable (see header comment)
+        hist_len[i] = len;
+    }
+    if (aux_accel) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
+        if (corr) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
+        }
+    }
+}
+
+// (Re)start the history with the single entry {x, u = 0, P} at tick n-1 (EKF.cpp:337-339), from the
+// state record; used by initialize_state and whenever the host overwrites the state.
+template <typename T>
+__global__ void k_hist_reset(MrParams m, const T* __restrict__ st, T* __restrict__ ring, int32_t* __restrict__ hist_len, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    T s[kSW];
+    load_rec<T, kSW, 0, kSW>(st, i, s);
+    T* sn = ring_slot(ring, m, m.tick - 1);
+    store_rec<T, kHWpad, 0, kSW>(sn, i, s);
+    const T uk[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
+    store_rec<T, kHWpad, kSW, 8>(sn, i, uk);
+    hist_len[i] = 1;
+}
+
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
 template <typename T, bool DIRECT, bool PFP>
 __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ st, const T* __restrict__ zs,

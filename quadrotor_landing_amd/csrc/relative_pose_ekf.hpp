@@ -102,20 +102,21 @@ public:
     RelativePoseEKF(const RelativePoseEKF&) = delete;
     RelativePoseEKF& operator=(const RelativePoseEKF&) = delete;
 
-    // Perform periodic EKF filter update (relative_pose_EKF.hpp:26, .cpp:127-303; single-rate branch)
-    void filter_update(double /*t_curr*/)
+    // Perform periodic EKF filter update (relative_pose_EKF.hpp:26, .cpp:127-303; single-rate and multirate)
+    void filter_update(double t_curr)
     {
         if (!state_initialized) return;  // .cpp:129-130
         double u[6] = {IMU_accel[0], IMU_accel[1], IMU_accel[2], IMU_ang_vel[0], IMU_ang_vel[1], IMU_ang_vel[2]};
         double z[7] = {apriltag_pos[0], apriltag_pos[1], apriltag_pos[2], apriltag_orien[0], apriltag_orien[1], apriltag_orien[2], apriltag_orien[3]};
         const uint8_t ready = measurement_ready ? 1 : 0;
-        check(qle_filter_update(h_, u, ready ? z : nullptr, ready ? &ready : nullptr));
+        check(qle_filter_update_stamped(h_, u, ready ? z : nullptr, ready ? &ready : nullptr, t_curr, &apriltag_time));
         uint8_t perf = 0, cons = 0;
         int32_t upds = 0;
         check(qle_get_tick_flags(h_, &perf, &cons, &upds));
         if (cons) measurement_ready = false;  // .cpp:152
         performed_correction = perf != 0;     // .cpp:301
         upds_since_correction = upds;         // .cpp:292-299
+        if (perf && multirate_ekf) check(qle_get_measurement_delay(h_, &measurement_delay_curr));  // .cpp:199
         pull();
         filter_active = true;                 // .cpp:302
     }
@@ -134,8 +135,6 @@ public:
     void initialize_params()
     {
         qle_params p = to_params();
-        if (p.multirate_ekf)
-            throw Error(QLE_ERR_INVALID, "multirate_ekf: the delayed-measurement replay (relative_pose_EKF.cpp:196-236) is not implemented");
         qle_derived d;
         check(qle_params_derive(&p, &d));
         if (!h_) {

@@ -20,6 +20,7 @@ struct SynthArgs {
     int64_t filter_offset;
     double ab_sigma, wb_sigma, meas_scale, imu_scale;
     int32_t perturb, est_bias;
+    int32_t meas_delay_ticks, _pad;   // tag pose delivered at tick t was taken meas_delay_ticks-1 ticks earlier (multirate runs)
     double dT;
     double Q[12], R[6], g[3], r_v_cv[3], q_vc[4], C_vc[9], ab_static[3], wb_static[3];
     int64_t T, B, pitch_u_words, pitch_z_words;
@@ -48,6 +49,7 @@ __device__ inline double rng_normal(uint64_t seed, uint64_t filter, uint64_t tic
     return sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2);
 }
 
+constexpr int kSynthMaxDelay = 40;
 constexpr uint64_t kTickStatic = 0xFFFFFFFFFFFFFFF0ULL;  // per-filter constants
 constexpr uint64_t kTickSeedMeas = 0xFFFFFFFFFFFFFFF1ULL; // noise of the seeding tag pose
 
@@ -151,6 +153,13 @@ __global__ void k_synth(SynthArgs a, const int32_t* __restrict__ slot, T* __rest
         for (int k = 0; k < 7; ++k) z0[word_off<T>(k, i, kZW)] = (T)z[k];
         z0[word_off<T>(7, i, kZW)] = T(1);
     }
+    // truth poses of the last ticks, for delayed tag poses: entry (t+1) % N = pose after tick t
+    constexpr int N = kSynthMaxDelay + 1;
+    double rh[N][3], qh[N][4];
+    for (int k = 0; k < N; ++k) {
+        for (int c = 0; c < 3; ++c) rh[k][c] = r[c];
+        for (int c = 0; c < 4; ++c) qh[k][c] = s.q[c];
+    }
     for (int64_t t = 0; t < a.T; ++t) {
         const double tt = (double)t * a.dT;
         double acc[3], w[3], C[9];
@@ -175,10 +184,23 @@ __global__ void k_synth(SynthArgs a, const int32_t* __restrict__ slot, T* __rest
         quat_norm<double>(qn);
         for (int k = 0; k < 4; ++k) s.q[k] = qn[k];
         for (int k = 0; k < 3; ++k) r[k] = s.r0[k] + s.A[k] * sin(s.om[k] * (tt + a.dT) + s.ph[k]);
+        {
+            const int e = (int)((t + 1) % N);
+            for (int c = 0; c < 3; ++c) rh[e][c] = r[c];
+            for (int c = 0; c < 4; ++c) qh[e][c] = s.q[c];
+        }
         const int32_t sl = slot[t];
-        if (sl >= 0) {  // tag pose of the state the filter holds after this tick's predict
+        if (sl >= 0) {
+            // single-rate (delay 0): the pose the filter holds after this tick's predict.
+            // multirate with step delay L: the filter fuses it into history entry "tick t-L",
+            // i.e. the pose after tick t-L (EKF.cpp:201-209).
+            int64_t tm = t - a.meas_delay_ticks;
+            if (tm < -1) tm = -1;
+            const int e = (int)((tm + 1) % N);
+            const double rr[3] = {rh[e][0], rh[e][1], rh[e][2]};
+            const double qq[4] = {qh[e][0], qh[e][1], qh[e][2], qh[e][3]};
             double z[7];
-            synth_measure(a, gi, (uint64_t)t, r, s.q, a.R, z);
+            synth_measure(a, gi, (uint64_t)t, rr, qq, a.R, z);
             T* zt = zs + (int64_t)sl * a.pitch_z_words;
             for (int k = 0; k < 7; ++k) zt[word_off<T>(k, i, kZW)] = (T)z[k];
             zt[word_off<T>(7, i, kZW)] = T(1);

@@ -170,11 +170,26 @@ class BatchedRelativePoseEKF:
     def enable_gating(self, on=True):
         check(lib().qle_enable_gating(self._h, int(bool(on))))
 
-    def filter_update(self, u, z=None, measurement_ready=None):
-        """One filter_update tick: rate limit + corner gate + predict (+ correct) per filter."""
+    def filter_update(self, u, z=None, measurement_ready=None, t_curr=None, apriltag_time=None):
+        """One filter_update tick: rate limit + corner gate + predict (+ correct) per filter; with
+        multirate_ekf the correction goes to the delayed history entry and the predicts are replayed.
+        t_curr / apriltag_time [batch] feed dynamic_meas_delay (relative_pose_EKF.cpp:199)."""
         m = _u8(measurement_ready, (self.batch,))
         zz = None if z is None else _f64(z, (self.batch, 7))
-        check(lib().qle_filter_update(self._h, _dp(_f64(u, (self.batch, 6))), _dp(zz), None if m is None else m.ctypes.data_as(_pu8)))
+        mp = None if m is None else m.ctypes.data_as(_pu8)
+        if t_curr is None:
+            check(lib().qle_filter_update(self._h, _dp(_f64(u, (self.batch, 6))), _dp(zz), mp))
+        else:
+            st = None if apriltag_time is None else _f64(apriltag_time, (self.batch,))
+            check(lib().qle_filter_update_stamped(self._h, _dp(_f64(u, (self.batch, 6))), _dp(zz), mp, float(t_curr), _dp(st)))
+
+    def measurement_delay(self):
+        out = np.zeros(self.batch)
+        check(lib().qle_get_measurement_delay(self._h, _dp(out)))
+        return out
+
+    def set_uniform_measurement_age(self, seconds):
+        check(lib().qle_set_uniform_measurement_age(self._h, float(seconds)))
 
     def tick_flags(self):
         """(performed_correction, consumed, upds_since_correction) after the last tick."""

@@ -132,3 +132,33 @@ def test_product_never_imports_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.lower() or f == "__never__", f"{f} mentions the oracle"
+
+
+def test_shipped_parameter_files_load():
+    cfg = os.path.join(ROOT, "quadrotor_landing_amd", "config")
+    p = qla.load_yaml(os.path.join(cfg, "ekf_sim_rotors.yaml"))
+    d = qla.derive(p)
+    assert (p.update_freq, p.measurement_freq, d.upd_per_meas, d.measurement_step_delay) == (100.0, 15.0, 7, 3)
+    assert p.limit_measurement_freq == 1 and p.multirate_ekf == 1 and p.n_tags == 1 and p.camera_width == 752
+    assert list(p.Q_a) == [5e-4] * 3 and list(p.R_ang) == [0.0015, 0.0015, 0.04]
+    p = qla.load_yaml(os.path.join(cfg, "ekf_hardware.yaml"))
+    d = qla.derive(p)
+    assert (d.upd_per_meas, d.measurement_step_delay, p.n_tags, p.camera_width, p.camera_height) == (1, 15, 13, 640, 480)
+    assert list(p.ab_static) == [0.20, -0.09, -0.03] and p.tag_in_view_margin == 0.0
+    assert list(p.tag_positions)[36:39] == [-0.314325, 0.0, 0.0] and list(p.tag_widths)[:2] == [0.08382, 0.16764]
+    assert abs(np.linalg.norm(list(d.q_vc)) - 1) < 1e-15
+
+
+def test_cpp_driver_parses_config_and_fails_loudly_without_gpu():
+    import subprocess
+    exe = os.path.join(ROOT, "quadrotor_landing_amd", "ekf_driver")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc")], check=True)
+    n = C.c_int32(-1)
+    if _lib.lib().qle_device_count(C.byref(n)) == 0 and n.value > 0:
+        pytest.skip("a GPU is present")
+    r = subprocess.run([exe, "--config", os.path.join(ROOT, "quadrotor_landing_amd", "config", "ekf_hardware.yaml"), "--batch", "8", "--ticks", "10"],
+                       capture_output=True, text=True)
+    assert r.returncode == 1 and "no CPU fallback" in r.stderr
+    r = subprocess.run([exe, "--config", "/nonexistent.yaml"], capture_output=True, text=True)
+    assert r.returncode == 2

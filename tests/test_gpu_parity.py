@@ -454,8 +454,95 @@ def test_filter_update_gating_matches_reference_logic(cfg, dtype):
         assert_state_close(xg, Pg, xr, Pr, 1e-10, 1e-12, 1e-10)
     else:
         assert_state_close(xg, Pg, xr, Pr, 5e-4, 5e-4, 5e-4)
-    # multirate is refused loudly rather than silently run single-rate
-    ekf2 = qla.BatchedRelativePoseEKF(4, dtype, multirate_ekf=1)
-    with pytest.raises(qla.QleError):
-        ekf2.enable_gating(True)
-    ekf.close(); ekf2.close()
+    ekf.close()
+
+
+# -------------------------------------------------- multirate EKF (replay)
+def _oracle_filters(po, x, P):
+    filt = []
+    for i in range(x.shape[0]):
+        f = oracle.Filter(po)
+        for k in range(3):
+            f.f.apriltag_pos[k] = 0.0
+        # seed through the reference's own path so that the history starts as initialize_state leaves it
+        f.f.state_initialized = 0
+        filt.append(f)
+    return filt
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("cfg", [dict(dynamic_meas_delay=0, measurement_delay=0.030, limit_measurement_freq=1, measurement_freq=30.0),
+                                 dict(dynamic_meas_delay=1, measurement_delay=0.030, measurement_delay_max=0.200,
+                                      dyn_measurement_delay_offset=0.005, limit_measurement_freq=1, measurement_freq=15.0),
+                                 dict(dynamic_meas_delay=1, measurement_delay=0.150, measurement_delay_max=0.350,
+                                      dyn_measurement_delay_offset=0.085, limit_measurement_freq=0, **HW_TAGS)])
+def test_multirate_replay_matches_reference_logic(cfg, dtype):
+    """multirate_ekf = true (EKF.cpp:196-236, 251-264) against the oracle's full filter object: delayed
+    correction index, history trimming, replay of the stored IMU samples, dynamic delay per filter."""
+    kw = dict(update_freq=100.0, direct_orien_method=1, multirate_ekf=1, corner_margin_enbl=1, **cfg)
+    po, pq = both(**kw)
+    rng = np.random.default_rng(77)
+    B, T = 64, 60
+    z0 = np.zeros((B, 7))
+    z0[:, 0:2] = rng.normal(size=(B, 2)) * 0.1; z0[:, 2] = rng.uniform(0.8, 2.0, size=B)
+    z0[:, 3:7] = np.array([0.7071067811865476, -0.7071067811865476, 0.0, 0.0])
+    if dtype == "f32":
+        z0 = z0.astype(np.float32).astype(np.float64)
+    ekf = qla.BatchedRelativePoseEKF(B, dtype, params=pq)
+    ekf.enable_gating(True)
+    ekf.initialize_state(z0, reinit_bias=True)
+    filt = []
+    for i in range(B):
+        f = oracle.Filter(po)
+        f.set_apriltag(z0[i, :3], z0[i, 3:], -1.0)   # initialises the state and the history (EKF.cpp:305-344)
+        f.f.measurement_ready = 0
+        filt.append(f)
+    if dtype == "f32":  # start both from the engine's (fp32-rounded) seeded state
+        xs, Ps = ekf.get_state()
+        for i, f in enumerate(filt):
+            for k in range(3):
+                f.f.r_nom[k] = xs[i, k]
+            for k in range(4):
+                f.f.q_nom[k] = xs[i, 6 + k]
+            for k in range(16):
+                f.f.x_hist[k] = xs[i, k]
+    pending = np.zeros(B, np.uint8)
+    zlast = z0.copy(); stamp = np.zeros(B)
+    n_perf = 0
+    for t in range(T):
+        tc = 0.01 * t
+        u = rand_imu(rng, B) * np.array([0.05, 0.05, 1, 0.2, 0.2, 0.2])
+        new = rng.uniform(size=B) < 0.45
+        xs = ekf.get_state()[0]
+        znew = meas_near(rng, po, xs, ang=0.2, pos=0.05)
+        znew[:, 0:2] += rng.choice([0.0, 0.0, 0.0, 1.5], size=(B, 1)) * rng.normal(size=(B, 2))
+        if dtype == "f32":
+            u = u.astype(np.float32).astype(np.float64); znew = znew.astype(np.float32).astype(np.float64)
+        zlast[new] = znew[new]
+        stamp[new] = tc - rng.uniform(0.0, 0.3, size=int(new.sum()))  # camera latency 0..300 ms, per filter
+        pending |= new.astype(np.uint8)
+        for i in range(B):
+            filt[i].set_imu(u[i, :3], u[i, 3:])
+            if new[i]:
+                filt[i].set_apriltag(zlast[i, :3], zlast[i, 3:], stamp[i])
+            filt[i].filter_update(tc)
+        ekf.filter_update(u, zlast if pending.any() else None, pending if pending.any() else None, t_curr=tc, apriltag_time=stamp)
+        perf, cons, upds = ekf.tick_flags()
+        ref_perf = np.array([f.f.performed_correction for f in filt], np.uint8)
+        np.testing.assert_array_equal(perf, ref_perf)
+        np.testing.assert_array_equal(upds, np.array([f.f.upds_since_correction for f in filt], np.int32))
+        pending &= (1 - cons)
+        np.testing.assert_array_equal(pending, np.array([f.f.measurement_ready for f in filt], np.uint8))
+        if perf.any() and cfg["dynamic_meas_delay"]:
+            d = ekf.measurement_delay()
+            ref_d = np.array([f.f.measurement_delay_curr for f in filt])
+            np.testing.assert_allclose(d[perf.astype(bool)], ref_d[perf.astype(bool)], atol=1e-12)
+        n_perf += int(perf.sum())
+        xg, Pg = ekf.get_state()
+        xr = np.stack([f.x() for f in filt]); Pr = np.stack([f.P() for f in filt])
+        if dtype == "f64":
+            assert_state_close(xg, Pg, xr, Pr, 1e-10, 1e-12, 1e-10)
+        else:
+            assert_state_close(xg, Pg, xr, Pr, 1e-3, 1e-3, 1e-3)
+    assert n_perf > B
+    ekf.close()
