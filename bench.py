@@ -101,7 +101,14 @@ def main():
         import torch
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
+    import ctypes
     import quadrotor_landing_amd as qla
+
+    ndev = ctypes.c_int32(0)
+    qla.lib().qle_device_count(ctypes.byref(ndev))
+    # one rank per GPU; a rehearsal with more ranks than devices (1-GPU box) wraps around and says so
+    device = local_rank % max(ndev.value, 1)
+    oversubscribed = world > max(ndev.value, 1)
 
     B, K, W = args.batch_per_gpu, args.steps, args.warmup
     upd = 14  # ceil(400/30), relative_pose_EKF.cpp:91
@@ -109,7 +116,7 @@ def main():
     T = max(upd, (T // upd) * upd)  # whole measurement periods so the wrapped schedule stays periodic
     thm = np.zeros(T, np.uint8); thm[upd - 1::upd] = 1
 
-    ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=local_rank, **CFG3)
+    ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, **CFG3)
     seq = ekf.make_inputs(T, thm)
     ekf.synth_generate(seq, seed=0xE4F00003, filter_offset=rank * B)
     x0 = P0 = None
@@ -170,7 +177,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "cfg3: 65536 filters/GPU, 400 Hz IMU predict + 30 Hz tag-pose update (every 14th tick fused), ROTORS noise set",
                    "batch_per_gpu": B, "global_batch": world * B, "ticks_resident_in_hbm": T,
-                   "parallelism": f"filters sharded x{world}, no collectives"},
+                   "parallelism": f"filters sharded x{world}, no collectives"
+                                  + (f" (REHEARSAL: {world} ranks on {ndev.value} device(s))" if oversubscribed else "")},
         "roofline": {"bound": "hbm", "kernel": "k_predict", "achieved": p_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p_bytes, "avg_launch_us": p_ms / Kp * 1e3, "launches": Kp,
