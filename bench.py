@@ -80,13 +80,31 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
-    ap.add_argument("--warmup", type=int, default=56)
+    ap.add_argument("--warmup", type=int, default=60)
     ap.add_argument("--batch-per-gpu", type=int, default=65536)
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seq-ticks", type=int, default=0, help="ticks of generated input kept in HBM (0 = steps+warmup, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--predict-only-steps", type=int, default=2000)
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
+                    help="cfg3 (default, the metric's configuration); cfg2 = 4096 fp64 filters, update on every tick, 100 Hz; "
+                         "cfg5 = Monte-Carlo sweep: per-filter perturbed Q / static biases, per-device RMSE (32768 filters per GPU)")
     args = ap.parse_args()
+    cfg = dict(CFG3)
+    upd = 14  # ceil(400/30), relative_pose_EKF.cpp:91
+    perturb = False
+    if args.workload == "cfg2":
+        cfg.update(update_freq=100.0, measurement_freq=100.0, limit_measurement_freq=0)
+        upd = 1
+        args.dtype = "f64"
+        if args.batch_per_gpu == 65536:
+            args.batch_per_gpu = 4096
+        if args.steps == 4000:
+            args.steps, args.warmup = 1000, 20
+    elif args.workload == "cfg5":
+        perturb = True
+        if args.batch_per_gpu == 65536:
+            args.batch_per_gpu = 32768
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -111,16 +129,16 @@ def main():
     oversubscribed = world > max(ndev.value, 1)
 
     B, K, W = args.batch_per_gpu, args.steps, args.warmup
-    upd = 14  # ceil(400/30), relative_pose_EKF.cpp:91
     T = args.seq_ticks or min(K + W, 4200)
     T = max(upd, (T // upd) * upd)  # whole measurement periods so the wrapped schedule stays periodic
     thm = np.zeros(T, np.uint8); thm[upd - 1::upd] = 1
 
-    ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, **CFG3)
+    ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, **cfg)
     seq = ekf.make_inputs(T, thm)
-    ekf.synth_generate(seq, seed=0xE4F00003, filter_offset=rank * B)
+    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg5": 0xE4F00005}[args.workload]
+    ekf.synth_generate(seq, seed=seed, filter_offset=rank * B, perturb_filter_params=perturb)
     x0 = P0 = None
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    if rank == 0 and not args.no_cpu_baseline and world == 1 and args.workload == "cfg3":
         x0, P0 = ekf.get_state()
 
     def barrier():
@@ -145,23 +163,31 @@ def main():
     n_upd = sum(int(thm[(W + k) % T]) for k in range(K))
     bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * ekf.algorithmic_bytes(1)
     bad = ekf.count_nonfinite()
+    # per-device error sums vs the generator's truth at the end of the resident sequence (cfg 5 reduction);
+    # meaningful when the run ended on the sequence's last tick, reported in any case
+    rm = ekf.synth_rmse(seq) if (W + K) % T == 0 else None
+    if rm is not None and dist is not None:
+        rt = torch.tensor(rm, dtype=torch.float64)
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM)   # 3 scalars per device, combined on the host
+        rm = rt.numpy()
 
-    # dominant kernel (k_predict: 13 of every 14 launches) on its own, HIP events on its stream
+    # dominant kernel (k_predict: 13 of every 14 launches) on its own: the same conditions as the timed
+    # region (a long generated sequence, fresh inputs every tick) minus the fused ticks; HIP events on
+    # the stream the kernel is launched on.  Re-seeds the filters, so it runs after everything else.
     Kp = args.predict_only_steps
-    pseq = ekf.make_inputs(upd - 1, None)
-    for t in range(upd - 1):
-        u, _, _ = seq.download_tick(t)
-        pseq.upload_tick(t, u)
+    Tp = min(Kp, 2000)
+    pseq = ekf.make_inputs(Tp, None)
+    ekf.synth_generate(pseq, seed=seed + 1, filter_offset=rank * B, perturb_filter_params=perturb)
     ekf.run(pseq, 0, 20)
     ekf.synchronize()
     ekf.timer_begin()
-    ekf.run(pseq, 0, Kp)
+    ekf.run(pseq, 20, Kp)
     p_ms = ekf.timer_end()
     p_bytes = ekf.algorithmic_bytes(0)
     p_gbs = p_bytes / (p_ms / Kp * 1e-3) / 1e9
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath) and args.workload == "cfg3" and B == 65536 and args.dtype == "f32":  # measured for this configuration only
         try:
             traffic = json.load(open(tpath)).get("k_predict_hbm_bytes_per_launch")
         except Exception:
@@ -175,7 +201,9 @@ def main():
         "ms_per_step": wall / K * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": "cfg3: 65536 filters/GPU, 400 Hz IMU predict + 30 Hz tag-pose update (every 14th tick fused), ROTORS noise set",
+        "config": {"workload": {"cfg3": "cfg3: 65536 filters/GPU, 400 Hz IMU predict + 30 Hz tag-pose update (every 14th tick fused), ROTORS noise set",
+                                "cfg2": "cfg2: 4096 fp64 filters, predict + update on every tick (100 Hz), ROTORS noise set",
+                                "cfg5": "cfg5: Monte-Carlo sweep, per-filter Q scaled by 10^U(-0.5,0.5) and static biases, 400 Hz predict + 30 Hz update"}[args.workload],
                    "batch_per_gpu": B, "global_batch": world * B, "ticks_resident_in_hbm": T,
                    "parallelism": f"filters sharded x{world}, no collectives"
                                   + (f" (REHEARSAL: {world} ranks on {ndev.value} device(s))" if oversubscribed else "")},
@@ -183,9 +211,13 @@ def main():
                      "frac": p_gbs / HBM_PEAK_GBS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": p_bytes, "avg_launch_us": p_ms / Kp * 1e3, "launches": Kp,
                      "mixed_achieved": bytes_mixed / (ev_ms * 1e-3) / 1e9,
-                     "mixed_note": "all K timed launches (13 k_predict : 1 k_step), HIP-event time incl. inter-launch gaps"},
+                     "mixed_note": f"all K timed launches ({K - n_upd} k_predict : {n_upd} k_step), HIP-event time incl. inter-launch gaps"},
         "nonfinite_filters": bad,
     }
+    if rm is not None:
+        from quadrotor_landing_amd.sharding import combine_rmse
+        r_r, r_th, n = combine_rmse([rm])
+        out["rmse_vs_truth"] = {"position_m": r_r, "attitude_rad": r_th, "filters": n}
     if x0 is not None:
         out["cpu_baseline"] = cpu_baseline(seq, x0, P0, min(B, 65536), 140)
     if rank == 0:

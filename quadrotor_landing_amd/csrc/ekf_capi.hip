@@ -136,6 +136,7 @@ struct qle_batch {
     int32_t dtype = QLE_F32;
     int32_t device = 0;
     int32_t block = 256;
+    int32_t nt = 0;        // cache policy of the hot kernels' streaming accesses (0 default, 2 non-temporal)
     size_t wsz = 4;
     qle_params pub;
     qle_derived der;
@@ -289,6 +290,14 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     h->dtype = dtype;
     h->device = device;
     h->wsz = dtype == QLE_F32 ? 4 : 8;
+    {   // Cache policy, measured on MI355X (profiles/r01_tuning.md): non-temporal loads+stores are faster
+        // when the state is about the size of the aggregate L2 or smaller (shorter kernel boundaries: less
+        // dirty L2 to flush) and when it is far larger than the 256 MiB Infinity Cache (pure streaming);
+        // in between, the default policy keeps the state resident in the Infinity Cache.
+        const double state_mib = (double)kSW * (double)h->Bp * (double)h->wsz / (1024.0 * 1024.0);
+        h->nt = (state_mib <= 38.0 || state_mib >= 300.0) ? 2 : 0;
+        if (const char* s = std::getenv("QLE_NT")) h->nt = std::atoi(s) >= 1 ? 2 : 0;
+    }
     if (const char* s = std::getenv("QLE_BLOCK")) {
         int b = std::atoi(s);
         if (b == 64 || b == 128 || b == 256) h->block = b;
@@ -496,8 +505,13 @@ static int launch_predict(qle_batch* h, const void* u)
     const dim3 g = grid_for(h, h->block), b(h->block);
     T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on) hipLaunchKernelGGL((k_predict<T, true>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-    else hipLaunchKernelGGL((k_predict<T, false>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+    if (h->nt) {
+        if (h->pfp_on) hipLaunchKernelGGL((k_predict<T, true, 2>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+        else hipLaunchKernelGGL((k_predict<T, false, 2>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+    } else {
+        if (h->pfp_on) hipLaunchKernelGGL((k_predict<T, true, 0>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+        else hipLaunchKernelGGL((k_predict<T, false, 0>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+    }
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
@@ -531,10 +545,10 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     const dim3 g = grid_for(h, h->block), b(h->block);
     T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on)
-        hipLaunchKernelGGL((k_step<T, DIRECT, true, GATE>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B);
-    else
-        hipLaunchKernelGGL((k_step<T, DIRECT, false, GATE>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B);
+#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B)
+    if (h->nt) { if (h->pfp_on) QLE_STEP_LAUNCH(true, 2); else QLE_STEP_LAUNCH(false, 2); }
+    else { if (h->pfp_on) QLE_STEP_LAUNCH(true, 0); else QLE_STEP_LAUNCH(false, 0); }
+#undef QLE_STEP_LAUNCH
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
@@ -607,6 +621,24 @@ static int launch_update(qle_batch* h, const void* z)
     return h->pub.direct_orien_method ? launch_update_d<T, true>(h, z) : launch_update_d<T, false>(h, z);
 }
 
+// One filter_update tick has been launched.  Tick indices are 32-bit on the device
+// (last_corr, ring slot = tick % C); long before they could wrap, shift the origin by a
+// multiple of the ring capacity so that slots and differences are unchanged.
+static int advance_tick(qle_batch* h)
+{
+    h->tick++;
+    if (h->tick >= (int64_t)1 << 30) {
+        const int64_t C = h->mr_C > 0 ? h->mr_C : 1;
+        const int64_t shift = (((int64_t)1 << 29) / C) * C;
+        if (h->last_corr) {
+            hipLaunchKernelGGL(k_rebase_ticks, grid_for(h, 256), dim3(256), 0, h->stream, h->last_corr, (int32_t)shift, h->B);
+            HIP_TRY(hipGetLastError());
+        }
+        h->tick -= shift;
+    }
+    return QLE_OK;
+}
+
 static int need_state(const qle_batch* h)
 {
     if (!h->state_set) return fail(QLE_ERR_STATE, "state not initialised: call qle_set_state or qle_initialize_state first (EKF.cpp:129-130)");
@@ -644,8 +676,7 @@ extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const ui
         QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
         QLE_TRY(BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z));
     }
-    h->tick++;
-    return QLE_OK;
+    return advance_tick(h);
 }
 
 // ---- device-side gating: the full single-rate filter_update decision logic ----
@@ -901,7 +932,7 @@ extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n
         } else {
             QLE_TRY(BY_DTYPE(h, launch_step, h, u_at(in, t), z_at(in, s)));
         }
-        h->tick++;
+        QLE_TRY(advance_tick(h));
     }
     return QLE_OK;
 }

@@ -337,6 +337,177 @@ __device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T
     }
 }
 
+// ------------------------------------------------- predict, levelled variant
+// Same arithmetic as ekf_predict, organised for a memory-bound single wave per SIMD: the new
+// covariance Pn is computed block-row by block-row from the OLD P, bottom-up
+//   level 0: rows ab, wb    (need old rows ab, wb)
+//   level 1: rows th        (need old rows th, ab, wb)
+//   level 2: rows v         (need old rows v, th, ab, wb)
+//   level 3: rows r         (need old rows r, v)
+// and `done(level)` is called after each level so the caller can issue that level's stores while
+// the loads of the rows above are still in flight (the caller issues the loads bottom-up too).
+// F = L3 L2 L1 as in ekf_predict; the formulas below are the composition written out per block.
+template <typename T, typename Done>
+__device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], const T (&P)[120],
+                                                   const T (&u)[6], T (&accel)[3], T (&Pn)[120], Done done)
+{
+#define QLE_PN(i, j) Pn[::qle::sidx((i), (j))]
+    const T dT = p.dT, dTw = p.dTw;
+    T a[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = u[i] - x[10 + i] - nz.ab_static[i];
+        w[i] = u[3 + i] - x[13 + i] - nz.wb_static[i];
+    }
+    T q[4] = {x[6], x[7], x[8], x[9]};
+    T C[9];
+    quat_to_rot(q, C);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) accel[i] = (C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]) + p.g[i];
+    T dw[3] = {dT * w[0], dT * w[1], dT * w[2]};
+    T qe[4], qn[4];
+    quat_exp(dw, qe);
+    quat_mul(q, qe, qn);
+    quat_norm(qn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x[i] += dT * x[3 + i];
+        x[3 + i] += dT * accel[i];
+    }
+    x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+    done(-1);  // x is final
+
+    T X[3][6];
+    const T mdT = -dT, mdTb = -dT * p.bias_on;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        T c0 = C[3 * i], c1 = C[3 * i + 1], c2 = C[3 * i + 2];
+        X[i][0] = mdT * (c1 * a[2] - c2 * a[1]);
+        X[i][1] = mdT * (c2 * a[0] - c0 * a[2]);
+        X[i][2] = mdT * (c0 * a[1] - c1 * a[0]);
+        X[i][3] = mdTb * c0; X[i][4] = mdTb * c1; X[i][5] = mdTb * c2;
+    }
+    T Rt[3][3];
+    {
+        T ang = t_sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
+        bool small = ang < p.small_ang_tol;
+        T inv = T(1) / (small ? T(1) : ang);
+        T ax[3] = {dw[0] * inv, dw[1] * inv, dw[2] * inv};
+        T sn, cs;
+        t_sincos(-ang, &sn, &cs);
+        T sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+        T ca[3] = {(T(1) - cs) * ax[0], (T(1) - cs) * ax[1], (T(1) - cs) * ax[2]};
+        T t01 = ca[0] * ax[1], t02 = ca[0] * ax[2], t12 = ca[1] * ax[2];
+        Rt[0][0] = small ? T(1) : ca[0] * ax[0] + cs;
+        Rt[1][1] = small ? T(1) : ca[1] * ax[1] + cs;
+        Rt[2][2] = small ? T(1) : ca[2] * ax[2] + cs;
+        Rt[0][1] = small ? dw[2] : t01 - sa[2];
+        Rt[1][0] = small ? -dw[2] : t01 + sa[2];
+        Rt[0][2] = small ? -dw[1] : t02 + sa[1];
+        Rt[2][0] = small ? dw[1] : t02 - sa[1];
+        Rt[1][2] = small ? dw[0] : t12 - sa[0];
+        Rt[2][1] = small ? -dw[0] : t12 + sa[0];
+    }
+
+    // ---- level 0: rows ab (9..11), wb (12..14) ----------------------------
+#pragma unroll
+    for (int i = 9; i < 15; ++i) {
+#pragma unroll
+        for (int k = i; k < 15; ++k) QLE_PN(i, k) = QLE_PS(i, k);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        QLE_PN(9 + i, 9 + i) += nz.Q[6 + i];
+        QLE_PN(12 + i, 12 + i) += nz.Q[9 + i];
+    }
+    done(0);
+
+    // ---- level 1: rows th (6..8) -----------------------------------------
+    {
+        T Mtt[3][3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                // th,wb and th,ab: Rt O_t* - dTw O_w*
+                QLE_PN(6 + i, 12 + c) = (Rt[i][0] * QLE_PS(6, 12 + c) + Rt[i][1] * QLE_PS(7, 12 + c) + Rt[i][2] * QLE_PS(8, 12 + c)) - dTw * QLE_PS(12 + i, 12 + c);
+                QLE_PN(6 + i, 9 + c) = (Rt[i][0] * QLE_PS(6, 9 + c) + Rt[i][1] * QLE_PS(7, 9 + c) + Rt[i][2] * QLE_PS(8, 9 + c)) - dTw * QLE_PS(12 + i, 9 + c);
+                Mtt[i][c] = (Rt[i][0] * QLE_PS(6, 6 + c) + Rt[i][1] * QLE_PS(7, 6 + c) + Rt[i][2] * QLE_PS(8, 6 + c)) - dTw * QLE_PS(12 + i, 6 + c);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int k = i; k < 3; ++k)
+                QLE_PN(6 + i, 6 + k) = (Mtt[i][0] * Rt[k][0] + Mtt[i][1] * Rt[k][1] + Mtt[i][2] * Rt[k][2]) - dTw * QLE_PN(6 + i, 12 + k) +
+                                       ((i == k) ? nz.Q[3 + i] : T(0));
+        }
+    }
+    done(1);
+
+    // ---- level 2: rows v (3..5) --------------------------------------------
+    {
+        T Mv[3][9];  // M_v,[th ab wb] = O_v* + X O_[th ab],*
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 9; ++c) {
+                T acc = QLE_PS(3 + i, 6 + c);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += X[i][m] * QLE_PS(6 + m, 6 + c);
+                Mv[i][c] = acc;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                QLE_PN(3 + i, 12 + c) = Mv[i][6 + c];
+                QLE_PN(3 + i, 9 + c) = Mv[i][3 + c];
+                QLE_PN(3 + i, 6 + c) = (Mv[i][0] * Rt[c][0] + Mv[i][1] * Rt[c][1] + Mv[i][2] * Rt[c][2]) - dTw * Mv[i][6 + c];
+            }
+#pragma unroll
+            for (int k = i; k < 3; ++k) {
+                T acc = QLE_PS(3 + i, 3 + k);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += X[i][m] * QLE_PS(3 + k, 6 + m);
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += Mv[i][m] * X[k][m];
+                acc += C[3 * i] * nz.Q[0] * C[3 * k] + C[3 * i + 1] * nz.Q[1] * C[3 * k + 1] + C[3 * i + 2] * nz.Q[2] * C[3 * k + 2];
+                QLE_PN(3 + i, 3 + k) = acc;
+            }
+        }
+    }
+    done(2);
+
+    // ---- level 3: rows r (0..2) --------------------------------------------
+    {
+        T M1[3][12];  // M1_r,[v th ab wb] = O_r* + dT O_v*
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 12; ++c) M1[i][c] = QLE_PS(i, 3 + c) + dT * QLE_PS(3 + i, 3 + c);
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                QLE_PN(i, 12 + c) = M1[i][9 + c];
+                QLE_PN(i, 9 + c) = M1[i][6 + c];
+                QLE_PN(i, 6 + c) = (M1[i][3] * Rt[c][0] + M1[i][4] * Rt[c][1] + M1[i][5] * Rt[c][2]) - dTw * M1[i][9 + c];
+                T acc = M1[i][c];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) acc += M1[i][3 + m] * X[c][m];
+                QLE_PN(i, 3 + c) = acc;
+            }
+#pragma unroll
+            for (int k = i; k < 3; ++k) QLE_PN(i, k) = QLE_PS(i, k) + dT * (QLE_PS(k, 3 + i) + M1[i][k]);
+        }
+    }
+    done(3);
+#undef QLE_PN
+}
+
 // ------------------------------------------------------------------- update
 // correction_step, EKF.cpp:417-502.  z = [r_c_tc(3), q_ct(x,y,z,w)(4)].
 // obs receives r_t_vt_obs(3), q_tv_obs(4) (members written at EKF.cpp:431-443).

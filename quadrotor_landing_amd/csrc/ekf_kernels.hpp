@@ -39,14 +39,33 @@ constexpr int kUW = 6;      // IMU words
 constexpr int kZW = 8;      // tag pose 7 words + mask word
 constexpr int kFW = 24;     // per-filter parameter words
 
+// 16-byte quads as native vectors (global_load/store_dwordx4).  NT selects the cache policy of the
+// streaming state/input accesses of the hot kernels: 0 = default, 2 = non-temporal loads and stores.
+// Every state byte is read once and written once per launch; which policy is faster depends on
+// whether the state fits the 256 MiB Infinity Cache (chosen per handle, see ekf_capi.hip).
+typedef float qle_f4 __attribute__((ext_vector_type(4)));
+typedef double qle_d2 __attribute__((ext_vector_type(2)));
+typedef float qle_f2 __attribute__((ext_vector_type(2)));
 template <typename T> struct Quad;
-template <> struct Quad<float> { using type = float4; static constexpr int VW = 4; };
-template <> struct Quad<double> { using type = double2; static constexpr int VW = 2; };
+template <> struct Quad<float> { using type = qle_f4; static constexpr int VW = 4; };
+template <> struct Quad<double> { using type = qle_d2; static constexpr int VW = 2; };
 
-__device__ __forceinline__ void unpack_quad(const float4& v, float* r) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
-__device__ __forceinline__ void unpack_quad(const double2& v, double* r) { r[0] = v.x; r[1] = v.y; }
-__device__ __forceinline__ float4 pack_quad(const float* r) { return make_float4(r[0], r[1], r[2], r[3]); }
-__device__ __forceinline__ double2 pack_quad(const double* r) { return make_double2(r[0], r[1]); }
+template <int NT, typename Q>
+__device__ __forceinline__ Q ld_quad(const Q* ptr)
+{
+    if (NT >= 2) return __builtin_nontemporal_load(ptr);
+    return *ptr;
+}
+template <int NT, typename Q>
+__device__ __forceinline__ void st_quad(Q* ptr, Q v)
+{
+    if (NT >= 1) __builtin_nontemporal_store(v, ptr);
+    else *ptr = v;
+}
+__device__ __forceinline__ void unpack_quad(const qle_f4& v, float* r) { r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w; }
+__device__ __forceinline__ void unpack_quad(const qle_d2& v, double* r) { r[0] = v.x; r[1] = v.y; }
+__device__ __forceinline__ qle_f4 pack_quad(const float* r) { qle_f4 v = {r[0], r[1], r[2], r[3]}; return v; }
+__device__ __forceinline__ qle_d2 pack_quad(const double* r) { qle_d2 v = {r[0], r[1]}; return v; }
 
 // Number of filters a record array must be allocated for (whole tiles).
 __host__ __device__ inline int64_t padded_filters(int64_t B) { return (B + kTile - 1) / kTile * kTile; }
@@ -65,9 +84,14 @@ __host__ __device__ inline int64_t word_off(int w, int64_t i, int WT)
     return base + (int64_t)nf * VW * kTile + lane * rem + (w - nf * VW);
 }
 
+// Tile index of filter i, as a wave-uniform (SGPR) value: the 64 lanes of a wave always belong to one
+// tile (blocks are multiples of 64 threads), so the tile base can live in scalar registers and the
+// loads/stores use the scalar-base + per-lane-offset addressing form instead of 64-bit VALU adds.
+__device__ __forceinline__ int64_t wave_tile(int64_t i) { return (int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 6)); }
+
 // Load words [W0, W0+W) of filter i's WT-word record.  W0 and W are whole quads,
 // except that the load may end with the record's 8-byte tail row (fp32 only).
-template <typename T, int WT, int W0, int W>
+template <typename T, int WT, int W0, int W, int NT = 0>
 __device__ __forceinline__ void load_rec(const T* __restrict__ base, int64_t i, T (&r)[W])
 {
     using Q = typename Quad<T>::type;
@@ -77,33 +101,33 @@ __device__ __forceinline__ void load_rec(const T* __restrict__ base, int64_t i, 
     constexpr int REM = W % VW;
     static_assert(W0 % VW == 0, "loads start on a quad row");
     static_assert(REM == 0 || (REM == 2 && W0 + W == WT && W0 / VW + NF == NFT), "only the record's own 8-byte tail may be partial");
-    const int64_t tile = i >> 6;
+    const int64_t tile = wave_tile(i);
     const int lane = (int)(i & 63);
     const T* tb = base + tile * (int64_t)(WT * kTile);
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        Q v = *reinterpret_cast<const Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW);
+        Q v = ld_quad<NT>(reinterpret_cast<const Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW));
         unpack_quad(v, &r[k * VW]);
     }
     if (REM == 2) {
-        float2 v = *reinterpret_cast<const float2*>(tb + NFT * VW * kTile + lane * 2);
+        qle_f2 v = ld_quad<NT>(reinterpret_cast<const qle_f2*>(tb + NFT * VW * kTile + lane * 2));
         r[NF * VW] = v.x;
         r[NF * VW + 1] = v.y;
     }
 }
 
-template <typename T, int WT, int W0, int W>
+template <typename T, int WT, int W0, int W, int NT = 0>
 __device__ __forceinline__ void store_rec(T* __restrict__ base, int64_t i, const T (&r)[W])
 {
     using Q = typename Quad<T>::type;
     constexpr int VW = Quad<T>::VW;
     constexpr int NF = W / VW;
     static_assert(W % VW == 0 && W0 % VW == 0, "stored ranges are whole quads");
-    const int64_t tile = i >> 6;
+    const int64_t tile = wave_tile(i);
     const int lane = (int)(i & 63);
     T* tb = base + tile * (int64_t)(WT * kTile);
 #pragma unroll
-    for (int k = 0; k < NF; ++k) *reinterpret_cast<Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW) = pack_quad(&r[k * VW]);
+    for (int k = 0; k < NF; ++k) st_quad<NT>(reinterpret_cast<Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW), pack_quad(&r[k * VW]));
 }
 
 template <typename T, bool PFP>
@@ -126,6 +150,34 @@ __device__ __forceinline__ void load_noise(const DevParams<T>& p, const T* __res
 #pragma unroll
         for (int k = 0; k < 6; ++k) nz.R[k] = p.R[k];
     }
+}
+
+// Load / store a range of whole quad rows [Q0, Q1) of the packed P (record words kXW + 4q ..),
+// rows taken in DESCENDING order so that the bias rows (end of the row-major triangle) come first.
+template <typename T, int Q0, int Q1, int NT = 0>
+__device__ __forceinline__ void load_P_quads_desc(const T* __restrict__ st, int64_t i, T (&P)[kPW])
+{
+    using Q = typename Quad<T>::type;
+    constexpr int VW = Quad<T>::VW;
+    const int64_t tile = wave_tile(i);
+    const int lane = (int)(i & 63);
+    const T* tb = st + tile * (int64_t)(kSW * kTile);
+#pragma unroll
+    for (int k = Q1 - 1; k >= Q0; --k) {
+        Q v = ld_quad<NT>(reinterpret_cast<const Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW));
+        unpack_quad(v, &P[k * VW]);
+    }
+}
+template <typename T, int Q0, int Q1, int NT = 0>
+__device__ __forceinline__ void store_P_quads_desc(T* __restrict__ st, int64_t i, const T (&P)[kPW])
+{
+    using Q = typename Quad<T>::type;
+    constexpr int VW = Quad<T>::VW;
+    const int64_t tile = wave_tile(i);
+    const int lane = (int)(i & 63);
+    T* tb = st + tile * (int64_t)(kSW * kTile);
+#pragma unroll
+    for (int k = Q1 - 1; k >= Q0; --k) st_quad<NT>(reinterpret_cast<Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW), pack_quad(&P[k * VW]));
 }
 
 // --------------------------------------------------------- measurement gate
@@ -173,21 +225,45 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 
 // ------------------------------------------------------------- hot kernels
 // Predict tick: reads x16 + P120 + u6, writes x16 + P120 (278 words/filter).
-template <typename T, bool PFP>
+// Row-major packed P: rows r = words 0..41, v = 42..74, th = 75..98, ab = 99..113, wb = 114..119.
+// Loads are issued bottom-up and each block-row of the new P is stored as soon as it is final
+// (ekf_predict_levels), so the stores overlap the loads of the rows above inside the one wave a
+// SIMD holds at B = 65 536.  QLE_PREDICT_LEVELS=0 selects the in-place variant (ekf_predict).
+#ifndef QLE_PREDICT_LEVELS
+#define QLE_PREDICT_LEVELS 1
+#endif
+template <typename T, bool PFP, int NT>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, T* __restrict__ st, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3];
-    load_rec<T, kUW, 0, kUW>(us, i, u);
-    load_rec<T, kSW, 0, kXW>(st, i, x);
-    load_rec<T, kSW, kXW, kPW>(st, i, P);
+    load_rec<T, kUW, 0, kUW, NT>(us, i, u);
+    load_rec<T, kSW, 0, kXW, NT>(st, i, x);
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
+#if QLE_PREDICT_LEVELS
+    constexpr int VW = Quad<T>::VW;
+    constexpr int NQ = kPW / VW;
+    load_P_quads_desc<T, 0, NQ, NT>(st, i, P);
+    T Pn[kPW];
+    // first word of each block-row in the row-major triangle; a quad is final once every word in it is
+    constexpr int w_th = 75, w_v = 42, w_ab = 99;
+    constexpr int q_ab = (w_ab + VW - 1) / VW, q_th = (w_th + VW - 1) / VW, q_v = (w_v + VW - 1) / VW;
+    ekf_predict_levels<T>(p, nz, x, P, u, accel, Pn, [&](int level) {
+        if (level == -1) store_rec<T, kSW, 0, kXW, NT>(st, i, x);
+        else if (level == 0) store_P_quads_desc<T, q_ab, NQ, NT>(st, i, Pn);
+        else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(st, i, Pn);
+        else if (level == 2) store_P_quads_desc<T, q_v, q_th, NT>(st, i, Pn);
+        else store_P_quads_desc<T, 0, q_v, NT>(st, i, Pn);
+    });
+#else
+    load_rec<T, kSW, kXW, kPW, NT>(st, i, P);
     ekf_predict<T>(p, nz, x, P, u, accel);
-    store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_rec<T, kSW, kXW, kPW>(st, i, P);
+    store_rec<T, kSW, 0, kXW, NT>(st, i, x);
+    store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
+#endif
     if (aux_accel) {  // optional side output (wave-uniform), AoS [B][3] in the compute dtype
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
@@ -197,7 +273,7 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
 // Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290):
 // predict, then correct where the record's mask word is non-zero.
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
-template <typename T, bool DIRECT, bool PFP, bool GATE>
+template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
 __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, T* __restrict__ st, const T* __restrict__ us,
                                                  const T* __restrict__ zs, const T* __restrict__ pfp,
                                                  T* __restrict__ aux_accel, T* __restrict__ aux_obs,
@@ -205,11 +281,11 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    T x[kXW], P[kPW], u[kUW], zr[kZW], accel[3];
-    load_rec<T, kUW, 0, kUW>(us, i, u);
-    load_rec<T, kZW, 0, kZW>(zs, i, zr);
-    load_rec<T, kSW, 0, kXW>(st, i, x);
-    load_rec<T, kSW, kXW, kPW>(st, i, P);
+    T x[kXW], Po[kPW], P[kPW], u[kUW], zr[kZW], accel[3];
+    load_rec<T, kUW, 0, kUW, NT>(us, i, u);
+    load_rec<T, kZW, 0, kZW, NT>(zs, i, zr);
+    load_rec<T, kSW, 0, kXW, NT>(st, i, x);
+    load_P_quads_desc<T, 0, kPW / Quad<T>::VW, NT>(st, i, Po);
     bool corr = zr[7] != T(0);
     if (GATE) {  // the mask word means "measurement_ready"; decide here (EKF.cpp:147-186)
         const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
@@ -224,14 +300,14 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
     }
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
-    ekf_predict<T>(p, nz, x, P, u, accel);
+    ekf_predict_levels<T>(p, nz, x, Po, u, accel, P, [](int) {});
     T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
     if (corr) {
         T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
         ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
     }
-    store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_rec<T, kSW, kXW, kPW>(st, i, P);
+    store_rec<T, kSW, 0, kXW, NT>(st, i, x);
+    store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
     if (aux_accel) {  // optional side outputs (wave-uniform)
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
@@ -381,6 +457,16 @@ __global__ void k_hist_reset(MrParams m, const T* __restrict__ st, T* __restrict
     const T uk[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
     store_rec<T, kHWpad, kSW, 8>(sn, i, uk);
     hist_len[i] = 1;
+}
+
+// Shift the tick origin: subtract `shift` from every filter's last-correction index so that the
+// 32-bit tick arithmetic never wraps in a long-running service.  "Never / long ago" saturates.
+__global__ void k_rebase_ticks(int32_t* __restrict__ last_corr, int32_t shift, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    const int64_t v = (int64_t)last_corr[i] - shift;
+    last_corr[i] = (int32_t)(v < -(int64_t)(1 << 30) ? -(int64_t)(1 << 30) : v);
 }
 
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
