@@ -86,9 +86,10 @@ def main():
     ap.add_argument("--seq-ticks", type=int, default=0, help="ticks of generated input kept in HBM (0 = steps+warmup, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--predict-only-steps", type=int, default=2000)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5"],
+    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "cfg3mr"],
                     help="cfg3 (default, the metric's configuration); cfg2 = 4096 fp64 filters, update on every tick, 100 Hz; "
-                         "cfg5 = Monte-Carlo sweep: per-filter perturbed Q / static biases, per-device RMSE (32768 filters per GPU)")
+                         "cfg5 = Monte-Carlo sweep: per-filter perturbed Q / static biases, per-device RMSE (32768 filters per GPU); "
+                         "cfg3mr = cfg3 with multirate_ekf (delayed-measurement replay, 30 ms camera latency = 12 ticks)")
     args = ap.parse_args()
     cfg = dict(CFG3)
     upd = 14  # ceil(400/30), relative_pose_EKF.cpp:91
@@ -105,6 +106,12 @@ def main():
         perturb = True
         if args.batch_per_gpu == 65536:
             args.batch_per_gpu = 32768
+    mr_step = 0
+    if args.workload == "cfg3mr":
+        # delays of relative_pose_EKF_rotors.yaml:5-7 at 400 Hz: step delay int(0.030/0.0025 + 0.5) = 12 ticks
+        cfg.update(multirate_ekf=1, dynamic_meas_delay=1, measurement_delay=0.030, measurement_delay_max=0.200,
+                   dyn_measurement_delay_offset=0.005)
+        mr_step = 12
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -135,8 +142,10 @@ def main():
 
     ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, **cfg)
     seq = ekf.make_inputs(T, thm)
-    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg5": 0xE4F00005}[args.workload]
-    ekf.synth_generate(seq, seed=seed, filter_offset=rank * B, perturb_filter_params=perturb)
+    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg5": 0xE4F00005, "cfg3mr": 0xE4F00003}[args.workload]
+    if mr_step:
+        ekf.set_uniform_measurement_age(mr_step / cfg["update_freq"] - cfg["dyn_measurement_delay_offset"])
+    ekf.synth_generate(seq, seed=seed, filter_offset=rank * B, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
     x0 = P0 = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.workload == "cfg3":
         x0, P0 = ekf.get_state()
@@ -162,6 +171,12 @@ def main():
         wall, ev_ms = float(tt[0]), float(tt[1])
     n_upd = sum(int(thm[(W + k) % T]) for k in range(K))
     bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * ekf.algorithmic_bytes(1)
+    if mr_step:
+        # multirate correction tick per filter: read u6 + z8 + entry 136 + (step-1) stored samples (8 words each);
+        # write the corrected entry, step-1 replayed entries (136 each) and the new entry (144)
+        wsz = 4 if args.dtype == "f32" else 8
+        words = (6 + 8 + 136 + 8 * (mr_step - 1)) + (136 * mr_step + 144)
+        bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * words * wsz * B
     bad = ekf.count_nonfinite()
     # per-device error sums vs the generator's truth at the end of the resident sequence (cfg 5 reduction);
     # meaningful when the run ended on the sequence's last tick, reported in any case
@@ -177,7 +192,7 @@ def main():
     Kp = args.predict_only_steps
     Tp = min(Kp, 2000)
     pseq = ekf.make_inputs(Tp, None)
-    ekf.synth_generate(pseq, seed=seed + 1, filter_offset=rank * B, perturb_filter_params=perturb)
+    ekf.synth_generate(pseq, seed=seed + 1, filter_offset=rank * B, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
     ekf.run(pseq, 0, 20)
     ekf.synchronize()
     ekf.timer_begin()
@@ -203,7 +218,8 @@ def main():
         "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": {"cfg3": "cfg3: 65536 filters/GPU, 400 Hz IMU predict + 30 Hz tag-pose update (every 14th tick fused), ROTORS noise set",
                                 "cfg2": "cfg2: 4096 fp64 filters, predict + update on every tick (100 Hz), ROTORS noise set",
-                                "cfg5": "cfg5: Monte-Carlo sweep, per-filter Q scaled by 10^U(-0.5,0.5) and static biases, 400 Hz predict + 30 Hz update"}[args.workload],
+                                "cfg5": "cfg5: Monte-Carlo sweep, per-filter Q scaled by 10^U(-0.5,0.5) and static biases, 400 Hz predict + 30 Hz update",
+                                "cfg3mr": "cfg3 with multirate_ekf: 30 Hz tag poses arrive 12 ticks late, corrected in the history ring and replayed"}[args.workload],
                    "batch_per_gpu": B, "global_batch": world * B, "ticks_resident_in_hbm": T,
                    "parallelism": f"filters sharded x{world}, no collectives"
                                   + (f" (REHEARSAL: {world} ranks on {ndev.value} device(s))" if oversubscribed else "")},

@@ -145,7 +145,11 @@ struct qle_batch {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t Bp = 0;        // batch padded to whole 64-filter tiles
-    void* st = nullptr;    // state records: x (16 words) + packed P (120 words), wave tiles
+    // State storage: ring of C arrays of 144-word state records, slot = tick % C.  C = 1 for the
+    // single-rate filter (in place); C = max step delay + 1 for the multirate filter, where the
+    // ring is the history of EKF.hpp:62-64.  The state "now" is slot (tick-1) % C.
+    void* ring = nullptr;
+    int32_t C = 0;
     void* pfp = nullptr;   // [24 words] per-filter params, wave tiles
     bool pfp_on = false;
     bool aux = false;
@@ -165,9 +169,7 @@ struct qle_batch {
     // multirate EKF (EKF.cpp:196-236, 251-264)
     bool mr = false;               // pub.multirate_ekf
     bool hist_dirty = true;        // state was overwritten: restart the history at the next tick
-    int32_t mr_C = 0;              // ring capacity in slots
-    void* ring = nullptr;          // [C][tiles][144 words]
-    int32_t* hist_len = nullptr;   // [B]
+    int32_t* hist_first = nullptr; // [B] tick of each filter's oldest valid history entry
     double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
     double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
     double t_curr = 0.0, uniform_age = 0.0;
@@ -211,6 +213,16 @@ template <> const DevParams<double>& dev<double>(const qle_batch* h) { return h-
 
 static inline dim3 grid_for(const qle_batch* h, int block) { return dim3((unsigned)((h->B + block - 1) / block)); }
 
+static inline size_t slot_bytes(const qle_batch* h) { return (size_t)kSW * (size_t)h->Bp * h->wsz; }
+static inline int32_t slot_of(const qle_batch* h, int64_t tick)
+{
+    int64_t s = tick % h->C;
+    return (int32_t)(s < 0 ? s + h->C : s);
+}
+// state after the last executed tick / state the next tick writes
+static inline void* state_cur(const qle_batch* h) { return (char*)h->ring + slot_bytes(h) * (size_t)slot_of(h, h->tick - 1); }
+static inline void* state_next(const qle_batch* h) { return (char*)h->ring + slot_bytes(h) * (size_t)slot_of(h, h->tick); }
+
 static int check_handle(const qle_batch* h)
 {
     if (!h) return fail(QLE_ERR_INVALID, "handle is null");
@@ -230,27 +242,40 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
     h->der = d;
     h->pf = make_dev<float>(*p, d);
     h->pd = make_dev<double>(*p, d);
-    // multirate history ring: C = largest reachable step delay + 1 (EKF.cpp:199-201)
+    // State ring: C = 1 (single-rate) or largest reachable step delay + 1 (multirate, EKF.cpp:199-201)
     h->mr = p->multirate_ekf != 0;
+    int32_t C = 1;
     if (h->mr) {
         int32_t step_max = d.measurement_step_delay;
         if (p->dynamic_meas_delay) step_max = std::max((int32_t)(p->measurement_delay_max / d.dT_nom + 0.5), 1);
-        const int32_t C = step_max + 1;
-        if (C > h->mr_C) {
-            if (h->ring) { HIP_TRY(hipStreamSynchronize(h->stream)); HIP_TRY(hipFree(h->ring)); h->ring = nullptr; }
-            hipError_t e = hipMalloc(&h->ring, (size_t)C * kHWpad * (size_t)h->Bp * h->wsz);
-            if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "hipMalloc of the multirate history ring (%d slots x %lld filters): %s", C, (long long)h->Bp, hipGetErrorString(e));
-            h->mr_C = C;
+        C = step_max + 1;
+    }
+    if (C != h->C) {
+        void* nr = nullptr;
+        hipError_t e = hipMalloc(&nr, slot_bytes(h) * (size_t)C);
+        if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "hipMalloc of the state ring (%d slots x %lld filters): %s", C, (long long)h->Bp, hipGetErrorString(e));
+        if (h->ring) {  // keep the current state: it moves to the slot the new ring assigns to tick-1
+            int64_t sn = (h->tick - 1) % C;
+            if (sn < 0) sn += C;
+            HIP_TRY(hipMemcpyAsync((char*)nr + slot_bytes(h) * (size_t)sn, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream));
+            HIP_TRY(hipStreamSynchronize(h->stream));
+            HIP_TRY(hipFree(h->ring));
+        } else {
+            HIP_TRY(hipMemsetAsync(nr, 0, slot_bytes(h) * (size_t)C, h->stream));
         }
-        if (!h->hist_len) {
-            HIP_TRY(hipMalloc((void**)&h->hist_len, sizeof(int32_t) * (size_t)h->Bp));
+        h->ring = nr;
+        h->C = C;
+    }
+    if (h->mr) {
+        if (!h->hist_first) {
+            HIP_TRY(hipMalloc((void**)&h->hist_first, sizeof(int32_t) * (size_t)h->Bp));
             HIP_TRY(hipMalloc((void**)&h->stamp, sizeof(double) * (size_t)h->Bp));
             HIP_TRY(hipMalloc((void**)&h->delay_cur, sizeof(double) * (size_t)h->Bp));
             HIP_TRY(hipMemsetAsync(h->delay_cur, 0, sizeof(double) * (size_t)h->Bp, h->stream));
         }
-        h->hist_dirty = true;
         h->uniform_age = p->measurement_delay;
     }
+    h->hist_dirty = true;
     return QLE_OK;
 }
 
@@ -259,7 +284,7 @@ extern "C" int qle_destroy(qle_batch* h)
     if (!h) return QLE_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->st, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->ring, h->hist_len, h->stamp,
+    void* bufs[] = {h->ring, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->hist_first, h->stamp,
                     h->delay_cur};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -314,14 +339,12 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     } while (0)
     if (hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipEventCreate failed"));
     const size_t B = (size_t)h->Bp, w = h->wsz;
-    ALLOC(h->st, kSW * B * w);
     ALLOC(h->tick_u, kUW * B * w);
     ALLOC(h->tick_z, kZW * B * w);
     ALLOC(h->stage, (size_t)kStageDoubles * sizeof(double));
     ALLOC(h->stage_mask, (size_t)kStageFilters);
     ALLOC(h->counter, sizeof(unsigned long long));
 #undef ALLOC
-    if (hipMemsetAsync(h->st, 0, kSW * B * w, h->stream) != hipSuccess) return bail(fail(QLE_ERR_HIP, "hipMemsetAsync failed"));
     *out = h;
     return QLE_OK;
 }
@@ -333,7 +356,9 @@ extern "C" int32_t qle_num_states(const qle_batch* h) { return h ? h->der.num_st
 extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
 {   // packed P, SoA, one streamed tick
     if (!h) return 0;
-    int64_t words = kind == 0 ? (16 + 120 + 6) + (16 + 120) : kind == 1 ? (16 + 120 + 6 + 7) + (16 + 120) : (16 + 120 + 7) + (16 + 120);
+    // a multirate predict tick also writes the IMU sample into the new history entry (+6 words, +2 pad)
+    const int64_t wr = (16 + 120) + ((h->mr && kind == 0) ? 8 : 0);
+    int64_t words = kind == 0 ? (16 + 120 + 6) + wr : kind == 1 ? (16 + 120 + 6 + 7) + wr : (16 + 120 + 7) + wr;
     if (h->pfp_on) words += kFW;
     return words * (int64_t)h->wsz * h->B;
 }
@@ -439,8 +464,8 @@ extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
 {
     QLE_TRY(check_handle(h));
     if (!x || !P) return fail(QLE_ERR_INVALID, "x and P must be non-null");
-    QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, h->st, kSW, 0));
-    QLE_TRY(BY_DTYPE(h, pack_P, h, P, h->st));
+    QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, state_cur(h), kSW, 0));
+    QLE_TRY(BY_DTYPE(h, pack_P, h, P, state_cur(h)));
     h->state_set = true;
     h->hist_dirty = true;
     return QLE_OK;
@@ -448,8 +473,8 @@ extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
 extern "C" int qle_get_state(qle_batch* h, double* x, double* P)
 {
     QLE_TRY(check_handle(h));
-    if (x) QLE_TRY(BY_DTYPE(h, unpack_rows, h, h->st, kXW, kXW, x, kSW, 0));
-    if (P) QLE_TRY(BY_DTYPE(h, unpack_P, h, h->st, P));
+    if (x) QLE_TRY(BY_DTYPE(h, unpack_rows, h, state_cur(h), kXW, kXW, x, kSW, 0));
+    if (P) QLE_TRY(BY_DTYPE(h, unpack_P, h, state_cur(h), P));
     return QLE_OK;
 }
 
@@ -498,22 +523,43 @@ extern "C" int qle_get_aux(qle_batch* h, double* accel_rel, double* obs)
 }
 
 // -------------------------------------------------------------- hot launches
+// Restart the multirate history with the single entry "state now" (EKF.cpp:337-339).
+static int mr_prepare(qle_batch* h)
+{
+    if (h->mr && h->hist_dirty) {
+        hipLaunchKernelGGL(k_fill_i32, grid_for(h, 256), dim3(256), 0, h->stream, h->hist_first, (int32_t)(h->tick - 1), h->B);
+        HIP_TRY(hipGetLastError());
+    }
+    h->hist_dirty = false;
+    return QLE_OK;
+}
+
+// prediction_step from `src` into `dst`; keep_u: the record also stores the IMU sample (multirate history).
 template <typename T>
-static int launch_predict(qle_batch* h, const void* u)
+static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
+    T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->nt) {
-        if (h->pfp_on) hipLaunchKernelGGL((k_predict<T, true, 2>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-        else hipLaunchKernelGGL((k_predict<T, false, 2>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B)
+    if (keep_u) {
+        if (h->nt) { if (h->pfp_on) QLE_PRED(true, 2, true); else QLE_PRED(false, 2, true); }
+        else { if (h->pfp_on) QLE_PRED(true, 0, true); else QLE_PRED(false, 0, true); }
     } else {
-        if (h->pfp_on) hipLaunchKernelGGL((k_predict<T, true, 0>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
-        else hipLaunchKernelGGL((k_predict<T, false, 0>), g, b, 0, h->stream, p, st, (const T*)u, pfp, acc, h->B);
+        if (h->nt) { if (h->pfp_on) QLE_PRED(true, 2, false); else QLE_PRED(false, 2, false); }
+        else { if (h->pfp_on) QLE_PRED(true, 0, false); else QLE_PRED(false, 0, false); }
     }
+#undef QLE_PRED
     HIP_TRY(hipGetLastError());
     return QLE_OK;
+}
+// the predict of one filter tick: slot n-1 -> slot n (the same slot when C == 1)
+template <typename T>
+static int launch_predict(qle_batch* h, const void* u)
+{
+    QLE_TRY(mr_prepare(h));
+    return launch_predict_sd<T>(h, u, state_cur(h), state_next(h), h->mr);
 }
 
 static GateParams make_gate(const qle_batch* h)
@@ -543,7 +589,7 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     const DevParams<T>& p = dev<T>(h);
     const GateParams gp = make_gate(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
+    T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
 #define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B)
     if (h->nt) { if (h->pfp_on) QLE_STEP_LAUNCH(true, 2); else QLE_STEP_LAUNCH(false, 2); }
@@ -552,17 +598,16 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
-static MrParams make_mr(const qle_batch* h, bool has_meas)
+static MrParams make_mr(const qle_batch* h)
 {
     MrParams m;
     std::memset(&m, 0, sizeof(m));
-    m.C = h->mr_C;
+    m.C = h->C;
     m.tick = (int32_t)h->tick;
     m.fixed_step = h->der.measurement_step_delay;
     m.dynamic = h->pub.dynamic_meas_delay;
     m.gate = h->gating ? 1 : 0;
-    m.has_meas = has_meas ? 1 : 0;
-    m.slot_words = (int64_t)kHWpad * h->Bp;
+    m.slot_words = (int64_t)kSW * h->Bp;
     m.dT = h->der.dT_nom;
     m.offset = h->pub.dyn_measurement_delay_offset;
     m.delay_max = h->pub.measurement_delay_max;
@@ -571,23 +616,19 @@ static MrParams make_mr(const qle_batch* h, bool has_meas)
     return m;
 }
 
-// One multirate tick (predict-only when z == nullptr).
+// One multirate tick that carries tag poses (predict-only multirate ticks go through launch_predict).
 template <typename T>
 static int launch_step_mr(qle_batch* h, const void* u, const void* z)
 {
+    QLE_TRY(mr_prepare(h));
     const DevParams<T>& p = dev<T>(h);
     const GateParams gp = make_gate(h);
-    const MrParams m = make_mr(h, z != nullptr);
-    if (h->hist_dirty) {  // restart the history with the single entry {x, 0, P} (EKF.cpp:337-339)
-        hipLaunchKernelGGL((k_hist_reset<T>), grid_for(h, 256), dim3(256), 0, h->stream, m, (const T*)h->st, (T*)h->ring, h->hist_len, h->B);
-        HIP_TRY(hipGetLastError());
-        h->hist_dirty = false;
-    }
+    const MrParams m = make_mr(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
+    T *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
-#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, st, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_len, h->last_corr, h->flags, h->delay_cur, h->B)
+#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
     if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
     else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
 #undef QLE_MR_LAUNCH
@@ -608,7 +649,7 @@ static int launch_update_d(qle_batch* h, const void* z)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)h->st, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
+    T *st = (T*)state_cur(h), *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     if (h->pfp_on) hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
     else hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
@@ -628,12 +669,14 @@ static int advance_tick(qle_batch* h)
 {
     h->tick++;
     if (h->tick >= (int64_t)1 << 30) {
-        const int64_t C = h->mr_C > 0 ? h->mr_C : 1;
+        const int64_t C = h->C > 0 ? h->C : 1;
         const int64_t shift = (((int64_t)1 << 29) / C) * C;
-        if (h->last_corr) {
-            hipLaunchKernelGGL(k_rebase_ticks, grid_for(h, 256), dim3(256), 0, h->stream, h->last_corr, (int32_t)shift, h->B);
-            HIP_TRY(hipGetLastError());
-        }
+        int32_t* arrs[2] = {h->last_corr, h->hist_first};
+        for (int32_t* a : arrs)
+            if (a) {
+                hipLaunchKernelGGL(k_rebase_ticks, grid_for(h, 256), dim3(256), 0, h->stream, a, (int32_t)shift, h->B);
+                HIP_TRY(hipGetLastError());
+            }
         h->tick -= shift;
     }
     return QLE_OK;
@@ -652,7 +695,7 @@ extern "C" int qle_predict(qle_batch* h, const double* u)
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     h->hist_dirty = true;  // a bare prediction_step is not a filter tick: the multirate history restarts
-    return BY_DTYPE(h, launch_predict, h, h->tick_u);
+    return BY_DTYPE(h, launch_predict_sd, h, h->tick_u, state_cur(h), state_cur(h), false);
 }
 extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)
 {
@@ -670,8 +713,7 @@ extern "C" int qle_step(qle_batch* h, const double* u, const double* z, const ui
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     if (!z) {
-        if (h->mr) QLE_TRY(BY_DTYPE(h, launch_step_mr, h, h->tick_u, (const void*)nullptr));
-        else QLE_TRY(BY_DTYPE(h, launch_predict, h, h->tick_u));
+        QLE_TRY(BY_DTYPE(h, launch_predict, h, h->tick_u));
     } else {
         QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
         QLE_TRY(BY_DTYPE(h, launch_step, h, h->tick_u, h->tick_z));
@@ -759,7 +801,7 @@ template <typename T>
 static int seed_t(qle_batch* h, int reinit)
 {
     const qle_derived& d = h->der;
-    hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)h->st,
+    hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)state_cur(h),
                        (T)d.cov_init[0], (T)d.cov_init[3], (T)d.cov_init[6], (T)d.cov_init[9], (T)d.cov_init[12], reinit, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
@@ -786,7 +828,7 @@ static int report_t(qle_batch* h, double* pose, double* cov, double* vel, double
         double* s_cov = s_pose + n * 7;
         double* s_vel = s_cov + n * 36;
         double* s_bias = s_vel + n * 3;
-        hipLaunchKernelGGL((k_report_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->st,
+        hipLaunchKernelGGL((k_report_off<T>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, dev<T>(h), (const T*)state_cur(h),
                            h->pfp_on ? (const T*)h->pfp : (const T*)nullptr, s_pose, s_cov, s_vel, s_bias, i0, n);
         HIP_TRY(hipGetLastError());
         if (pose) HIP_TRY(hipMemcpyAsync(pose + i0 * 7, s_pose, (size_t)n * 7 * 8, hipMemcpyDeviceToHost, h->stream));
@@ -806,7 +848,7 @@ extern "C" int qle_get_report(qle_batch* h, double* pose, double* pose_cov, doub
 template <typename T>
 static int nonfinite_t(qle_batch* h)
 {
-    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->st, h->counter, h->B);
+    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)state_cur(h), h->counter, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
@@ -927,8 +969,7 @@ extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n
         const int64_t t = (t0 + k) % in->T;
         const int32_t s = in->slot[(size_t)t];
         if (s < 0) {
-            if (h->mr) QLE_TRY(BY_DTYPE(h, launch_step_mr, h, u_at(in, t), (const void*)nullptr));
-            else QLE_TRY(BY_DTYPE(h, launch_predict, h, u_at(in, t)));
+            QLE_TRY(BY_DTYPE(h, launch_predict, h, u_at(in, t)));
         } else {
             QLE_TRY(BY_DTYPE(h, launch_step, h, u_at(in, t), z_at(in, s)));
         }
@@ -1009,7 +1050,7 @@ extern "C" int qle_synth_generate(qle_batch* h, qle_inputs* in, const qle_synth_
 template <typename T>
 static int rmse_t(qle_batch* h, const qle_inputs* in, double* d_out)
 {
-    hipLaunchKernelGGL((k_rmse<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)h->st, (const double*)in->truth, d_out, h->B);
+    hipLaunchKernelGGL((k_rmse<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)state_cur(h), (const double*)in->truth, d_out, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }

@@ -13,9 +13,12 @@
 // A record whose length is not a multiple of VW (fp32 u: 6 words) ends in one
 // row of 8-byte halves.
 //
-// The filter state is ONE record of 136 words: x (16) followed by the packed
-// upper triangle of P (120).  One lane owns one filter; the record lives in
-// VGPRs for the whole tick.
+// The filter state is ONE record of 144 words: x (16), the packed upper triangle of P (120), and
+// the IMU sample that produced it (6 + 2 pad; only written by the multirate EKF, whose history
+// entries are exactly these records).  One lane owns one filter; x and P live in VGPRs for the
+// whole tick.  State storage is a ring of C such record arrays indexed by tick (slot = tick % C):
+// C = 1 for the single-rate filter (updated in place), C = max step delay + 1 for the multirate
+// filter, where the ring IS the history x_hist/u_hist/P_hist of the reference (EKF.hpp:62-64).
 #pragma once
 
 #include "ekf_device.hpp"
@@ -34,7 +37,8 @@ constexpr int kTile = 64;   // filters per tile = wavefront size
 template <typename T> struct PredictWaves { static constexpr int value = sizeof(T) == 4 ? QLE_PREDICT_WAVES_F32 : 1; };
 constexpr int kXW = 16;     // state words
 constexpr int kPW = 120;    // packed covariance words
-constexpr int kSW = kXW + kPW;  // state record
+constexpr int kUoff = kXW + kPW; // word offset of the stored IMU sample inside the state record
+constexpr int kSW = kXW + kPW + 8;  // state record: x, P, u(6) + 2 pad
 constexpr int kUW = 6;      // IMU words
 constexpr int kZW = 8;      // tag pose 7 words + mask word
 constexpr int kFW = 24;     // per-filter parameter words
@@ -232,38 +236,45 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 #ifndef QLE_PREDICT_LEVELS
 #define QLE_PREDICT_LEVELS 1
 #endif
-template <typename T, bool PFP, int NT>
-__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, T* __restrict__ st, const T* __restrict__ us,
+// `src` is the state at tick n-1, `dst` the state at tick n: the same array for the single-rate
+// filter (in place: every load of a lane is issued before its first store), two ring slots for the
+// multirate filter (MR: the record also keeps the IMU sample, EKF.cpp:254-256).
+template <typename T, bool PFP, int NT, bool MR>
+__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
-    load_rec<T, kSW, 0, kXW, NT>(st, i, x);
+    load_rec<T, kSW, 0, kXW, NT>(src, i, x);
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
 #if QLE_PREDICT_LEVELS
     constexpr int VW = Quad<T>::VW;
     constexpr int NQ = kPW / VW;
-    load_P_quads_desc<T, 0, NQ, NT>(st, i, P);
+    load_P_quads_desc<T, 0, NQ, NT>(src, i, P);
     T Pn[kPW];
     // first word of each block-row in the row-major triangle; a quad is final once every word in it is
     constexpr int w_th = 75, w_v = 42, w_ab = 99;
     constexpr int q_ab = (w_ab + VW - 1) / VW, q_th = (w_th + VW - 1) / VW, q_v = (w_v + VW - 1) / VW;
     ekf_predict_levels<T>(p, nz, x, P, u, accel, Pn, [&](int level) {
-        if (level == -1) store_rec<T, kSW, 0, kXW, NT>(st, i, x);
-        else if (level == 0) store_P_quads_desc<T, q_ab, NQ, NT>(st, i, Pn);
-        else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(st, i, Pn);
-        else if (level == 2) store_P_quads_desc<T, q_v, q_th, NT>(st, i, Pn);
-        else store_P_quads_desc<T, 0, q_v, NT>(st, i, Pn);
+        if (level == -1) store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
+        else if (level == 0) store_P_quads_desc<T, q_ab, NQ, NT>(dst, i, Pn);
+        else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(dst, i, Pn);
+        else if (level == 2) store_P_quads_desc<T, q_v, q_th, NT>(dst, i, Pn);
+        else store_P_quads_desc<T, 0, q_v, NT>(dst, i, Pn);
     });
 #else
-    load_rec<T, kSW, kXW, kPW, NT>(st, i, P);
+    load_rec<T, kSW, kXW, kPW, NT>(src, i, P);
     ekf_predict<T>(p, nz, x, P, u, accel);
-    store_rec<T, kSW, 0, kXW, NT>(st, i, x);
-    store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
+    store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
+    store_rec<T, kSW, kXW, kPW, NT>(dst, i, P);
 #endif
+    if (MR) {
+        const T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+        store_rec<T, kSW, kUoff, 8, NT>(dst, i, uk);
+    }
     if (aux_accel) {  // optional side output (wave-uniform), AoS [B][3] in the compute dtype
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
@@ -274,7 +285,7 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
 // predict, then correct where the record's mask word is non-zero.
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
 template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
-__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, T* __restrict__ st, const T* __restrict__ us,
+__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
                                                  const T* __restrict__ zs, const T* __restrict__ pfp,
                                                  T* __restrict__ aux_accel, T* __restrict__ aux_obs,
                                                  int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B)
@@ -323,23 +334,22 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
 // `step` ticks ago is fused into the state the filter held THEN, and the predictions since are
 // replayed with the stored IMU samples.
 //
-// History layout: the reference keeps per-filter vectors x_hist/u_hist/P_hist (EKF.hpp:62-64) whose
-// entries belong to consecutive ticks.  Here entry "tick n" of every filter lives in ring slot
-// n % C of one HBM array [C][tiles][142 words] (x16, P120 packed, u6), so filters with equal
-// delays read the same slot and stay coalesced; per filter only hist_len is kept.  The index the
+// History: the reference keeps per-filter vectors x_hist/u_hist/P_hist (EKF.hpp:62-64) whose
+// entries belong to consecutive ticks.  Here the entry "state after tick n" of every filter is
+// the state record in ring slot n % C, so the history costs nothing extra on predict-only ticks
+// (k_predict<MR> reads slot n-1 and writes slot n) and filters with equal delays read the same
+// slot and stay coalesced.  Per filter only hist_first[i], the tick of its oldest valid entry,
+// is kept; it changes only on corrections (the trim of EKF.cpp:214-219).  The index the
 // reference computes, ind = max(len - step, 0) (EKF.cpp:201), never reaches further back than
-// step_max = the largest step delay the parameters allow, so a ring of C >= step_max slots
-// reproduces the unbounded vectors exactly (entries beyond it are unreachable).
-constexpr int kHW = kSW + kUW;  // history record: state record + IMU sample
-constexpr int kHWpad = 144;     // padded to whole quads for fp32 and fp64
-
+// step_max = the largest step delay the parameters allow, so a ring of C = step_max + 1 slots
+// reproduces the unbounded vectors exactly (older entries are unreachable).
 struct MrParams {
     int32_t C;            // ring capacity (slots)
     int32_t tick;         // index n of this tick; the newest history entry is tick n-1
     int32_t fixed_step;   // measurement_step_delay (EKF.cpp:93) when !dynamic
     int32_t dynamic;      // dynamic_meas_delay (EKF.hpp:79)
     int32_t gate;         // 1: mask word = measurement_ready, decide on device; 0: mask word = perform
-    int32_t has_meas;     // 0: predict-only tick (no tag record to read)
+    int32_t _pad;
     int64_t slot_words;   // words per ring slot
     double dT, offset, delay_max, t_curr, uniform_age;  // EKF.cpp:199-200
 };
@@ -352,86 +362,77 @@ __device__ __forceinline__ T* ring_slot(T* ring, const MrParams& m, int32_t tick
     return ring + (int64_t)s * m.slot_words;
 }
 
+// A multirate tick that carries tag poses.  Lanes that correct: load history entry tick_m, fuse the
+// measurement there, replay the predictions tick_m+1 .. n-1 from the stored IMU samples, then predict
+// tick n.  Lanes that do not: plain predict from entry n-1.  One predict call site serves the replay
+// and the current tick: iteration k uses the IMU sample stored in entry base+k, the last iteration the
+// current sample.
 template <typename T, bool DIRECT, bool PFP>
-__global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* __restrict__ st, T* __restrict__ ring,
-                                                    const T* __restrict__ us, const T* __restrict__ zs, const T* __restrict__ pfp,
-                                                    const double* __restrict__ stamp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                                    int32_t* __restrict__ hist_len, int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags,
-                                                    double* __restrict__ delay_out, int64_t B)
+__global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* ring, const T* __restrict__ us,
+                                                    const T* __restrict__ zs, const T* __restrict__ pfp, const double* __restrict__ stamp,
+                                                    T* __restrict__ aux_accel, T* __restrict__ aux_obs, int32_t* __restrict__ hist_first,
+                                                    int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, double* __restrict__ delay_out,
+                                                    int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    T x[kXW], P[kPW], u[kUW], accel[3];
+    T x[kXW], P[kPW], u[kUW], accel[3] = {T(0), T(0), T(0)};
     T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
     load_rec<T, kUW, 0, kUW>(us, i, u);
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
-    int32_t len = hist_len[i];
-    bool corr = false;
-    T z[7];
-    if (m.has_meas) {
-        T zr[kZW];
-        load_rec<T, kZW, 0, kZW>(zs, i, zr);
-#pragma unroll
-        for (int k = 0; k < 7; ++k) z[k] = zr[k];
-        corr = zr[7] != T(0);
-        if (m.gate) {  // EKF.cpp:147-186
-            const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
-            bool ok = consume;
-            if (consume && gp.corner_enbl) {
-                const double zd[7] = {(double)zr[0], (double)zr[1], (double)zr[2], (double)zr[3], (double)zr[4], (double)zr[5], (double)zr[6]};
-                ok = corner_gate(gp, zd);
-            }
-            corr = ok;
-            if (ok) last_corr[i] = gp.tick;
-            flags[i] = (uint8_t)((ok ? 1 : 0) | (consume ? 2 : 0));
+    T zr[kZW];
+    load_rec<T, kZW, 0, kZW>(zs, i, zr);
+    bool corr = zr[7] != T(0);
+    if (m.gate) {  // EKF.cpp:147-186
+        const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
+        bool ok = consume;
+        if (consume && gp.corner_enbl) {
+            const double zd[7] = {(double)zr[0], (double)zr[1], (double)zr[2], (double)zr[3], (double)zr[4], (double)zr[5], (double)zr[6]};
+            ok = corner_gate(gp, zd);
         }
+        corr = ok;
+        if (ok) last_corr[i] = gp.tick;
+        flags[i] = (uint8_t)((ok ? 1 : 0) | (consume ? 2 : 0));
     }
+    int32_t base = m.tick - 1;  // entry the loop starts from; iterations run base+1 .. n
     if (corr) {
-        // EKF.cpp:199-201: delay -> step delay -> index of the entry the measurement belongs to
+        // EKF.cpp:199-201: delay -> step delay -> history entry the measurement belongs to
         int32_t step = m.fixed_step;
         if (m.dynamic) {
             const double age = stamp ? (m.t_curr - stamp[i]) : m.uniform_age;
             const double dcur = fmin(age + m.offset, m.delay_max);
-            if (delay_out) delay_out[i] = dcur;
+            delay_out[i] = dcur;
             step = (int32_t)(dcur / m.dT + 0.5);
             if (step < 1) step = 1;
         }
+        int32_t len = m.tick - hist_first[i];  // entries hist_first .. n-1
+        if (len > m.C) len = m.C;              // older ones have been overwritten and are unreachable
         int32_t ind = len - step;
         if (ind < 0) ind = 0;
-        const int32_t tick_m = (m.tick - 1) - (len - 1) + ind;
-        T* sm = ring_slot(ring, m, tick_m);
-        load_rec<T, kHWpad, 0, kXW>(sm, i, x);
-        load_rec<T, kHWpad, kXW, kPW>(sm, i, P);
-        ekf_update<T, DIRECT>(p, nz, x, P, z, obs);           // EKF.cpp:209
-        store_rec<T, kHWpad, 0, kXW>(sm, i, x);               // EKF.cpp:210-211
-        store_rec<T, kHWpad, kXW, kPW>(sm, i, P);
-        len -= ind;                                           // EKF.cpp:214-219
-        for (int32_t k = 1; k < len; ++k) {                   // EKF.cpp:222-226
-            T* sk = ring_slot(ring, m, tick_m + k);
-            T uk[8], foo[3];
-            load_rec<T, kHWpad, kSW, 8>(sk, i, uk);
-            const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
-            ekf_predict<T>(p, nz, x, P, u6, foo);
-            store_rec<T, kHWpad, 0, kXW>(sk, i, x);
-            store_rec<T, kHWpad, kXW, kPW>(sk, i, P);
-        }
+        base = (m.tick - len) + ind;           // tick_m
+        hist_first[i] = base;                  // EKF.cpp:214-219
+        T* sm = ring_slot(ring, m, base);
+        load_rec<T, kSW, 0, kXW>(sm, i, x);
+        load_rec<T, kSW, kXW, kPW>(sm, i, P);
+        const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+        ekf_update<T, DIRECT>(p, nz, x, P, z, obs);          // EKF.cpp:209
+        store_rec<T, kSW, 0, kXW>(sm, i, x);                  // EKF.cpp:210-211
+        store_rec<T, kSW, kXW, kPW>(sm, i, P);
     } else {
-        load_rec<T, kSW, 0, kXW>(st, i, x);                   // nominal state == newest history entry
-        load_rec<T, kSW, kXW, kPW>(st, i, P);
+        const T* sp = ring_slot(ring, m, base);
+        load_rec<T, kSW, 0, kXW>(sp, i, x);
+        load_rec<T, kSW, kXW, kPW>(sp, i, P);
     }
-    ekf_predict<T>(p, nz, x, P, u, accel);                    // EKF.cpp:249
-    store_rec<T, kSW, 0, kXW>(st, i, x);                      // EKF.cpp:258-263
-    store_rec<T, kSW, kXW, kPW>(st, i, P);
-    {   // EKF.cpp:254-256: append (x_check, u, P_check)
-        T* sn = ring_slot(ring, m, m.tick);
-        store_rec<T, kHWpad, 0, kXW>(sn, i, x);
-        store_rec<T, kHWpad, kXW, kPW>(sn, i, P);
-        const T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
-        store_rec<T, kHWpad, kSW, 8>(sn, i, uk);
-        len += 1;
-        if (len > m.C) len = m.C;  // the dropped entry is unreachable (see header comment)
-        hist_len[i] = len;
+    for (int32_t t = base + 1; t <= m.tick; ++t) {            // EKF.cpp:222-226, then :249
+        T* sk = ring_slot(ring, m, t);
+        T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+        if (t != m.tick) load_rec<T, kSW, kUoff, 8>(sk, i, uk);
+        const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
+        ekf_predict<T>(p, nz, x, P, u6, accel);
+        store_rec<T, kSW, 0, kXW>(sk, i, x);
+        store_rec<T, kSW, kXW, kPW>(sk, i, P);
+        if (t == m.tick) store_rec<T, kSW, kUoff, 8>(sk, i, uk);  // EKF.cpp:254-256
     }
     if (aux_accel) {
 #pragma unroll
@@ -443,20 +444,10 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     }
 }
 
-// (Re)start the history with the single entry {x, u = 0, P} at tick n-1 (EKF.cpp:337-339), from the
-// state record; used by initialize_state and whenever the host overwrites the state.
-template <typename T>
-__global__ void k_hist_reset(MrParams m, const T* __restrict__ st, T* __restrict__ ring, int32_t* __restrict__ hist_len, int64_t B)
+__global__ void k_fill_i32(int32_t* __restrict__ dst, int32_t v, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    T s[kSW];
-    load_rec<T, kSW, 0, kSW>(st, i, s);
-    T* sn = ring_slot(ring, m, m.tick - 1);
-    store_rec<T, kHWpad, 0, kSW>(sn, i, s);
-    const T uk[8] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)};
-    store_rec<T, kHWpad, kSW, 8>(sn, i, uk);
-    hist_len[i] = 1;
+    if (i < B) dst[i] = v;
 }
 
 // Shift the tick origin: subtract `shift` from every filter's last-correction index so that the

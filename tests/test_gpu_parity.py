@@ -546,3 +546,61 @@ def test_multirate_replay_matches_reference_logic(cfg, dtype):
             assert_state_close(xg, Pg, xr, Pr, 1e-3, 1e-3, 1e-3)
     assert n_perf > B
     ekf.close()
+
+
+# ------------------------------------------------------ API robustness
+def test_api_round_trips_and_error_paths():
+    pq = qla.make_params()
+    rng = np.random.default_rng(5)
+    B = 100
+    a = qla.BatchedRelativePoseEKF(B, "f64", params=pq)
+    b = qla.BatchedRelativePoseEKF(B, "f32", params=qla.make_params(update_freq=400.0))
+    # state round trip (fp64 exact, fp32 to rounding), two handles alive on the same device
+    x, P = rand_states(rng, B, 15)
+    a.set_state(x, P); b.set_state(x, P)
+    xa, Pa = a.get_state(); xb, Pb = b.get_state()
+    np.testing.assert_array_equal(xa, x); np.testing.assert_array_equal(Pa, P)
+    np.testing.assert_allclose(xb, x, rtol=1e-6, atol=1e-7); np.testing.assert_allclose(Pb, P, rtol=1e-6, atol=1e-8)
+    # a non-symmetric P is symmetrised as (P + P^T)/2
+    Pn = P.copy(); Pn[:, 0, 5] += 0.01
+    a.set_state(x, Pn)
+    np.testing.assert_allclose(a.get_state()[1], 0.5 * (Pn + Pn.transpose(0, 2, 1)), rtol=0, atol=1e-17)
+    # input sequences: upload / download round trip, slot bookkeeping, bounds
+    T = 9
+    thm = np.zeros(T, np.uint8); thm[[2, 7]] = 1
+    seq = a.make_inputs(T, thm)
+    U = rng.normal(size=(T, B, 6)); Z = rng.normal(size=(T, B, 7)); M = (rng.uniform(size=(T, B)) < 0.5).astype(np.uint8)
+    for t in range(T):
+        seq.upload_tick(t, U[t], Z[t] if thm[t] else None, M[t] if thm[t] else None)
+    for t in range(T):
+        u, z, m = seq.download_tick(t)
+        np.testing.assert_array_equal(u, U[t])
+        if thm[t]:
+            np.testing.assert_array_equal(z, Z[t]); np.testing.assert_array_equal(m, M[t])
+        else:
+            assert not m.any()
+    with pytest.raises(qla.QleError):
+        seq.upload_tick(T, U[0])                    # tick out of range
+    with pytest.raises(qla.QleError):
+        seq.upload_tick(0, U[0], Z[0])              # tick 0 has no measurement slot
+    with pytest.raises(qla.QleError):
+        seq.upload_tick(2, U[2])                    # tick 2 needs z
+    with pytest.raises(qla.QleError):
+        b.run(seq, 0, 1)                            # sequence belongs to another handle
+    with pytest.raises(qla.QleError):
+        a.synth_rmse(seq)                           # no generated truth in an uploaded sequence
+    # parameters can be changed between ticks (NODE.cpp:138 re-runs initialize_params)
+    u = rand_imu(rng, B)
+    a.set_state(x, P)
+    a.initialize_params(update_freq=400.0, Q_a=[1e-3, 2e-3, 3e-3])
+    a.step(u)
+    po = oracle.make_params(update_freq=400.0, Q_a=[1e-3, 2e-3, 3e-3])
+    xr, Pr, _ = oracle_predict_batch(po, x, P, u)
+    assert_state_close(*a.get_state(), xr, Pr, 1e-12, 1e-14, 1e-11)
+    # an absurd batch fails with a clean out-of-memory error, not a crash
+    with pytest.raises(qla.QleError) as e:
+        qla.BatchedRelativePoseEKF(2 ** 34, "f64", params=pq)
+    assert e.value.code in (-3, -2)
+    a.close(); b.close()
+    with pytest.raises(Exception):
+        a.predict(u)                                # closed handle
