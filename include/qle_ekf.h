@@ -207,6 +207,12 @@ int qle_inputs_download_tick(qle_inputs *in, int64_t t, double *u, double *z, ui
  * predict+update launch on ticks with one.  Asynchronous. */
 int qle_run(qle_batch *h, const qle_inputs *in, int64_t t0, int64_t n);
 
+/* The same ticks as qle_run in ONE launch, with every filter's x and P held in registers for
+ * all n ticks (single-rate filter, explicit masks).  HBM traffic is the state once plus the
+ * inputs, so this is not the streamed one-launch-per-tick unit of work the headline metric and
+ * the roofline figure are defined on; it is reported separately. */
+int qle_run_resident(qle_batch *h, const qle_inputs *in, int64_t t0, int64_t n);
+
 /* ---- synthetic truth + IMU + tag-pose generator (replaces the ROS inputs) --
  * SURVEY.md section 8(d) "synthetic inputs".  Values depend only on
  * (seed, global filter index, tick, channel): any sharding gives the same data. */

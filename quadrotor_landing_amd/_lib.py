@@ -97,6 +97,7 @@ SYMBOLS = {
     "qle_inputs_upload_tick": (C.c_int, [_vp, _i64, _pd, _pd, _pu8]),
     "qle_inputs_download_tick": (C.c_int, [_vp, _i64, _pd, _pd, _pu8]),
     "qle_run": (C.c_int, [_vp, _vp, _i64, _i64]),
+    "qle_run_resident": (C.c_int, [_vp, _vp, _i64, _i64]),
     "qle_synth_cfg_default": (C.c_int, [C.POINTER(QleSynthCfg)]),
     "qle_synth_generate": (C.c_int, [_vp, _vp, C.POINTER(QleSynthCfg)]),
     "qle_synth_rmse": (C.c_int, [_vp, _vp, _pd]),

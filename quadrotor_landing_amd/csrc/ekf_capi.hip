@@ -187,6 +187,7 @@ struct qle_inputs {
     void* z = nullptr;
     void* truth = nullptr;      // AoS [B][7] fp64: r(3), q(4) at the end of the sequence
     void* truth_bias = nullptr; // AoS [B][6] fp64
+    int32_t* d_slot = nullptr;  // the slot table on the device (qle_run_resident, generator)
     bool has_truth = false;
 };
 
@@ -238,17 +239,21 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
     if (!p) return fail(QLE_ERR_INVALID, "params is null");
     qle_derived d;
     QLE_TRY(qle_params_derive(p, &d));
-    h->pub = *p;
-    h->der = d;
-    h->pf = make_dev<float>(*p, d);
-    h->pd = make_dev<double>(*p, d);
-    // State ring: C = 1 (single-rate) or largest reachable step delay + 1 (multirate, EKF.cpp:199-201)
-    h->mr = p->multirate_ekf != 0;
+    // State ring: C = 1 (single-rate) or largest reachable step delay + 1 (multirate, EKF.cpp:199-201).
+    // Allocate first; the handle's parameters change only once everything needed exists.
+    const bool mr = p->multirate_ekf != 0;
     int32_t C = 1;
-    if (h->mr) {
+    if (mr) {
         int32_t step_max = d.measurement_step_delay;
         if (p->dynamic_meas_delay) step_max = std::max((int32_t)(p->measurement_delay_max / d.dT_nom + 0.5), 1);
         C = step_max + 1;
+    }
+    if (mr && !h->hist_first) {
+        hipError_t e = hipMalloc((void**)&h->hist_first, sizeof(int32_t) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->stamp, sizeof(double) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->delay_cur, sizeof(double) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMemsetAsync(h->delay_cur, 0, sizeof(double) * (size_t)h->Bp, h->stream);
+        if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "multirate bookkeeping arrays: %s", hipGetErrorString(e));
     }
     if (C != h->C) {
         void* nr = nullptr;
@@ -257,25 +262,23 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
         if (h->ring) {  // keep the current state: it moves to the slot the new ring assigns to tick-1
             int64_t sn = (h->tick - 1) % C;
             if (sn < 0) sn += C;
-            HIP_TRY(hipMemcpyAsync((char*)nr + slot_bytes(h) * (size_t)sn, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream));
-            HIP_TRY(hipStreamSynchronize(h->stream));
-            HIP_TRY(hipFree(h->ring));
+            e = hipMemcpyAsync((char*)nr + slot_bytes(h) * (size_t)sn, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) e = hipFree(h->ring);
         } else {
-            HIP_TRY(hipMemsetAsync(nr, 0, slot_bytes(h) * (size_t)C, h->stream));
+            e = hipMemsetAsync(nr, 0, slot_bytes(h) * (size_t)C, h->stream);
         }
+        if (e != hipSuccess) { (void)hipFree(nr); return fail(QLE_ERR_HIP, "state ring setup: %s", hipGetErrorString(e)); }
         h->ring = nr;
         h->C = C;
     }
-    if (h->mr) {
-        if (!h->hist_first) {
-            HIP_TRY(hipMalloc((void**)&h->hist_first, sizeof(int32_t) * (size_t)h->Bp));
-            HIP_TRY(hipMalloc((void**)&h->stamp, sizeof(double) * (size_t)h->Bp));
-            HIP_TRY(hipMalloc((void**)&h->delay_cur, sizeof(double) * (size_t)h->Bp));
-            HIP_TRY(hipMemsetAsync(h->delay_cur, 0, sizeof(double) * (size_t)h->Bp, h->stream));
-        }
-        h->uniform_age = p->measurement_delay;
-    }
-    h->hist_dirty = true;
+    h->pub = *p;
+    h->der = d;
+    h->pf = make_dev<float>(*p, d);
+    h->pd = make_dev<double>(*p, d);
+    h->mr = mr;
+    if (mr) h->uniform_age = p->measurement_delay;
+    h->hist_dirty = true;  // the multirate history restarts from the current state
     return QLE_OK;
 }
 
@@ -872,7 +875,7 @@ extern "C" int qle_inputs_destroy(qle_inputs* in)
 {
     if (!in) return QLE_OK;
     (void)hipSetDevice(in->device);
-    void* bufs[] = {in->u, in->z, in->truth, in->truth_bias};
+    void* bufs[] = {in->u, in->z, in->truth, in->truth_bias, in->d_slot};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     delete in;
@@ -899,6 +902,8 @@ extern "C" int qle_inputs_create(qle_batch* h, int64_t n_ticks, const uint8_t* t
     if (e == hipSuccess && in->n_slots) e = hipMalloc(&in->z, in->pitch_z * (size_t)in->n_slots);
     if (e == hipSuccess) e = hipMalloc(&in->truth, (size_t)h->B * 7 * sizeof(double));
     if (e == hipSuccess) e = hipMalloc(&in->truth_bias, (size_t)h->B * 6 * sizeof(double));
+    if (e == hipSuccess) e = hipMalloc((void**)&in->d_slot, sizeof(int32_t) * (size_t)n_ticks);
+    if (e == hipSuccess) e = hipMemcpy(in->d_slot, in->slot.data(), sizeof(int32_t) * (size_t)n_ticks, hipMemcpyHostToDevice);
     if (e != hipSuccess) {
         qle_inputs_destroy(in);
         return fail(QLE_ERR_NOMEM, "hipMalloc for %lld ticks of inputs: %s", (long long)n_ticks, hipGetErrorString(e));
@@ -978,6 +983,36 @@ extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n
     return QLE_OK;
 }
 
+// On-chip-resident variant: ONE launch advances every filter by n ticks with x and P held in
+// registers; HBM traffic is the state once plus the inputs.  Not the unit of work of the headline
+// metric (one launch per tick); reported separately.
+template <typename T>
+static int run_resident_t(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    const T* pfp = (const T*)h->pfp;
+    const int64_t pu = (int64_t)(in->pitch_u / h->wsz), pz = (int64_t)(in->pitch_z / h->wsz);
+#define QLE_RES(D, F) hipLaunchKernelGGL((k_run_resident<T, D, F>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_RES(true, true); else QLE_RES(true, false); }
+    else { if (h->pfp_on) QLE_RES(false, true); else QLE_RES(false, false); }
+#undef QLE_RES
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+extern "C" int qle_run_resident(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
+{
+    QLE_TRY(check_handle(h));
+    QLE_TRY(need_state(h));
+    if (!in || in->h != h) return fail(QLE_ERR_INVALID, "inputs do not belong to this handle");
+    if (t0 < 0 || n < 0) return fail(QLE_ERR_INVALID, "t0 and n must be >= 0");
+    if (h->mr || h->gating) return fail(QLE_ERR_STATE, "qle_run_resident covers the single-rate filter with explicit masks (no multirate_ekf, no device gating)");
+    if (n == 0) return QLE_OK;
+    QLE_TRY(BY_DTYPE(h, run_resident_t, h, in, t0, n));
+    for (int64_t k = 0; k < n; ++k) QLE_TRY(advance_tick(h));
+    return QLE_OK;
+}
+
 // ------------------------------------------------------ synthetic generator
 extern "C" int qle_synth_cfg_default(qle_synth_cfg* c)
 {
@@ -1014,11 +1049,9 @@ static int synth_t(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
     a.B = h->B;
     a.pitch_u_words = (int64_t)(in->pitch_u / h->wsz);
     a.pitch_z_words = (int64_t)(in->pitch_z / h->wsz);
-    // slot table on device
-    int32_t* d_slot = nullptr;
-    HIP_TRY(hipMalloc((void**)&d_slot, sizeof(int32_t) * (size_t)in->T));
-    hipError_t e = hipMemcpyAsync(d_slot, in->slot.data(), sizeof(int32_t) * (size_t)in->T, hipMemcpyHostToDevice, h->stream);
-    if (e == hipSuccess) {
+    const int32_t* d_slot = in->d_slot;
+    hipError_t e = hipSuccess;
+    {
         if (c->perturb_filter_params && !h->pfp) e = hipMalloc(&h->pfp, kFW * (size_t)h->Bp * h->wsz);
     }
     if (e == hipSuccess) {
@@ -1027,7 +1060,6 @@ static int synth_t(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
         e = hipGetLastError();
     }
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    (void)hipFree(d_slot);
     if (e != hipSuccess) return fail(QLE_ERR_HIP, "synthetic generator: %s", hipGetErrorString(e));
     if (c->perturb_filter_params) h->pfp_on = true;
     in->has_truth = true;

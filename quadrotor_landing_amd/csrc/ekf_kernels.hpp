@@ -450,6 +450,44 @@ __global__ void k_fill_i32(int32_t* __restrict__ dst, int32_t v, int64_t B)
     if (i < B) dst[i] = v;
 }
 
+// On-chip-resident multi-tick kernel: x and P stay in registers for n ticks of the single-rate
+// filter (predict every tick, correct where the tick has a tag record whose mask word is set).
+// Per tick only the 6-word IMU record (and the 8-word tag record on measurement ticks) is read;
+// the next tick's IMU record is loaded before the current tick's arithmetic.
+template <typename T, bool DIRECT, bool PFP>
+__global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, const T* __restrict__ us, const T* __restrict__ zs,
+                                                         const int32_t* __restrict__ slot, int64_t pitch_u, int64_t pitch_z, int64_t T_seq,
+                                                         int64_t t0, int64_t n, const T* __restrict__ pfp, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    T x[kXW], P[kPW], u[kUW], un[kUW], accel[3];
+    load_rec<T, kSW, 0, kXW>(st, i, x);
+    load_rec<T, kSW, kXW, kPW>(st, i, P);
+    Noise<T> nz;
+    load_noise<T, PFP>(p, pfp, i, nz);
+    int64_t t = t0 % T_seq;
+    load_rec<T, kUW, 0, kUW>(us + t * pitch_u, i, u);
+    for (int64_t k = 0; k < n; ++k) {
+        const int64_t tn = (t + 1 == T_seq) ? 0 : t + 1;
+        if (k + 1 < n) load_rec<T, kUW, 0, kUW>(us + tn * pitch_u, i, un);
+        const int32_t s = slot[t];  // wave-uniform
+        T zr[kZW];
+        if (s >= 0) load_rec<T, kZW, 0, kZW>(zs + (int64_t)s * pitch_z, i, zr);
+        ekf_predict<T>(p, nz, x, P, u, accel);
+        if (s >= 0 && zr[7] != T(0)) {
+            const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+            T obs[7];
+            ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
+        }
+#pragma unroll
+        for (int c = 0; c < kUW; ++c) u[c] = un[c];
+        t = tn;
+    }
+    store_rec<T, kSW, 0, kXW>(st, i, x);
+    store_rec<T, kSW, kXW, kPW>(st, i, P);
+}
+
 // Shift the tick origin: subtract `shift` from every filter's last-correction index so that the
 // 32-bit tick arithmetic never wraps in a long-running service.  "Never / long ago" saturates.
 __global__ void k_rebase_ticks(int32_t* __restrict__ last_corr, int32_t shift, int64_t B)

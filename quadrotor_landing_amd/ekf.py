@@ -220,6 +220,10 @@ class BatchedRelativePoseEKF:
     def run(self, inputs, t0, n):
         check(lib().qle_run(self._h, inputs._h, int(t0), int(n)))
 
+    def run_resident(self, inputs, t0, n):
+        """n ticks in one launch with the state held on-chip (reported separately from the per-tick metric)."""
+        check(lib().qle_run_resident(self._h, inputs._h, int(t0), int(n)))
+
     def synth_generate(self, inputs, seed, filter_offset=0, perturb_filter_params=False, **kw):
         c = QleSynthCfg()
         check(lib().qle_synth_cfg_default(C.byref(c)))

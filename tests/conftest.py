@@ -15,6 +15,15 @@ def pytest_configure(config):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+def pytest_sessionstart(session):
+    """Build the native pieces if they are missing (hipcc cross-compiles without a GPU; seconds for the oracle)."""
+    import subprocess
+    if not os.path.exists(os.path.join(ROOT, "quadrotor_landing_amd", "libqle_ekf.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc")], check=True)
+    if not os.path.exists(os.path.join(ROOT, "oracle", "libekf_oracle.so")):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
+
+
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN

@@ -604,3 +604,40 @@ def test_api_round_trips_and_error_paths():
     a.close(); b.close()
     with pytest.raises(Exception):
         a.predict(u)                                # closed handle
+
+
+# ------------------------------------ on-chip-resident multi-tick variant
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 5e-3)])
+def test_run_resident_matches_per_tick_path_and_oracle(dtype, tol):
+    kw = golden_kwargs("rotors400")
+    po, pq = both(**kw)
+    B, T = 300, 84
+    thm = np.zeros(T, np.uint8); thm[13::14] = 1
+    a = qla.BatchedRelativePoseEKF(B, dtype, params=pq)
+    seq = a.make_inputs(T, thm)
+    a.synth_generate(seq, seed=11)
+    # give the masks some structure: a third of the filters skip each measurement
+    rng = np.random.default_rng(2)
+    for t in np.nonzero(thm)[0]:
+        u, z, m = seq.download_tick(int(t))
+        seq.upload_tick(int(t), u, z, (rng.uniform(size=B) < 0.67).astype(np.uint8))
+    x0, P0 = a.get_state()
+    a.run(seq, 0, T)
+    xa, Pa = a.get_state()
+    a.set_state(x0, P0)
+    a.run_resident(seq, 0, 30)          # two launches, wrapping inside the sequence is allowed
+    a.run_resident(seq, 30, T - 30)
+    xb, Pb = a.get_state()
+    U = np.empty((T, B, 6)); Z = np.zeros((T, B, 7)); M = np.zeros((T, B), np.uint8)
+    for t in range(T):
+        U[t], Z[t], M[t] = seq.download_tick(t)
+    xr, Pr = oracle.run_batch(po, x0, P0, U, Z, M)
+    for xg, Pg in ((xa, Pa), (xb, Pb)):
+        assert quat_err(xg[:, 6:10], xr[:, 6:10]) < tol
+        keep = [i for i in range(16) if not 6 <= i < 10]
+        np.testing.assert_allclose(xg[:, keep], xr[:, keep], rtol=tol, atol=tol)
+        assert (np.linalg.norm(Pg - Pr, axis=(1, 2)) / np.linalg.norm(Pr, axis=(1, 2))).max() < tol
+    a.enable_gating(True)
+    with pytest.raises(qla.QleError):
+        a.run_resident(seq, 0, 1)       # covers the single-rate filter with explicit masks only
+    a.close()
