@@ -354,6 +354,63 @@ def main():
                        P_full_ticks=np.array(ticks), P_full=np.stack([Pfull[t] for t in ticks]))
     np.savez_compressed(os.path.join(OUT_DIR, "sequence_cases.npz"),
                         **{f"{ps}__{k}": v for ps, d in out.items() for k, v in d.items()})
+    # ---------------- full filter_update of the twin (PYEKF.py:172-337) ----------------
+    # multirate replay with the twin's fixed step delay (measurement_delay 0.050 s -> 5 ticks, PYEKF.py:59-60),
+    # rate limiting (upd_per_meas = ceil(100/10) = 10, PYEKF.py:58,184), single-tag corner gate
+    # (PYEKF.py:199-211).  The twin reads ROS message objects; plain namespaces stand in for them.
+    from types import SimpleNamespace as NS
+
+    def imu_msg(u):
+        return NS(linear_acceleration=NS(x=float(u[0]), y=float(u[1]), z=float(u[2])),
+                  angular_velocity=NS(x=float(u[3]), y=float(u[4]), z=float(u[5])))
+
+    def tag_msg(z):
+        return NS(detections=[NS(pose=NS(pose=NS(pose=NS(position=NS(x=float(z[0]), y=float(z[1]), z=float(z[2])),
+                                                         orientation=NS(x=float(z[3]), y=float(z[4]), z=float(z[5]), w=float(z[6]))))))])
+
+    out = {}
+    for name, mr in (("multirate", True), ("singlerate", False)):
+        f = pyekf.RelativePoseEKF(100.0, 10.0)
+        f.multirate_EKF = mr
+        T = 160
+        U = np.zeros((T, 6)); Z = np.zeros((T, 7)); NEW = np.zeros(T, dtype=np.uint8)
+        Xs = np.zeros((T, 16)); Pd = np.zeros((T, 15)); UPD = np.zeros(T, dtype=np.int32); RDY = np.zeros(T, dtype=np.uint8)
+        HL = np.zeros(T, dtype=np.int32)
+        # truth: vehicle ~2 m above the tag, slow motion, camera looking down
+        r0 = np.array([0.1, -0.05, 2.0]); A = np.array([0.15, 0.1, 0.2]); om = np.array([0.9, 0.7, 0.5]); ph = np.array([0.3, 1.1, 2.0])
+        q_t = rand_unit_quat(rng, 0.15)
+        g = np.array([0, 0, -9.8])
+        P_last = None
+        for t in range(T):
+            tt = t * f.dT
+            acc_t = -A * om * om * np.sin(om * tt + ph)
+            w_t = np.array([0.05, -0.04, 0.08]) * np.sin(np.array([0.8, 1.1, 0.6]) * tt)
+            C_t = tft.quaternion_matrix(q_t)[0:3, 0:3]
+            U[t, 0:3] = C_t.T @ (acc_t - g) + rng.normal(size=3) * 0.05
+            U[t, 3:6] = w_t + rng.normal(size=3) * 0.01
+            f.IMU_msg = imu_msg(U[t])
+            # a tag pose arrives on an irregular pattern; some of them far off-axis (rejected by the corner gate)
+            if t == 0 or (t > 2 and rng.uniform() < 0.35):
+                r_t = r0 + A * np.sin(om * tt + ph)
+                r_c, q_ct = meas_from_pose(f, tft, r_t, q_t, rng, 0.02, 0.01)
+                if t > 0 and rng.uniform() < 0.2:
+                    r_c = r_c + np.array([3.5, 0.0, 0.0])
+                Z[t, 0:3] = r_c; Z[t, 3:7] = q_ct; NEW[t] = 1
+                f.apriltag_msg = tag_msg(Z[t])
+                f.measurement_ready = True
+                if not f.state_initialized:
+                    f.initialize_state(False)
+            f.filter_update()
+            q_t = tft.quaternion_multiply(q_t, pyqh.quaternion_exp(f.dT * w_t)); q_t /= np.linalg.norm(q_t)
+            Xs[t] = np.concatenate([f.r_nom.flatten(), f.v_nom.flatten(), f.q_nom.flatten(), f.ab_nom.flatten(), f.wb_nom.flatten()])
+            Pd[t] = np.diag(f.cov_pert); UPD[t] = f.upds_since_correction; RDY[t] = 1 if f.measurement_ready else 0
+            HL[t] = len(f.x_hist)
+            P_last = f.cov_pert.copy()
+        out[name] = dict(u=U, z=Z, new=NEW, x_seq=Xs, P_diag_seq=Pd, upds=UPD, ready=RDY, hist_len=HL, P_final=P_last)
+        print(name, "corrections:", int((UPD == 0).sum()), "max history:", int(HL.max()))
+    np.savez_compressed(os.path.join(OUT_DIR, "filter_update_cases.npz"),
+                        **{f"{n}__{k}": v for n, d in out.items() for k, v in d.items()})
+
     with open(os.path.join(OUT_DIR, "param_sets.json"), "w") as fh:
         json.dump(PARAM_SETS, fh, indent=1)
     print("golden fixtures written to", OUT_DIR)

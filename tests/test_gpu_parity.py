@@ -641,3 +641,37 @@ def test_run_resident_matches_per_tick_path_and_oracle(dtype, tol):
     with pytest.raises(qla.QleError):
         a.run_resident(seq, 0, 1)       # covers the single-rate filter with explicit masks only
     a.close()
+
+
+@pytest.mark.parametrize("mode", ["multirate", "singlerate"])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_full_filter_update_against_reference_twin_golden(mode, dtype):
+    """Engine (device-side gating + multirate ring) directly against the reference twin's own
+    filter_update trajectory (tests/golden/filter_update_cases.npz)."""
+    d = np.load(f"{GOLDEN}/filter_update_cases.npz")
+    U, Z, NEW = d[f"{mode}__u"], d[f"{mode}__z"], d[f"{mode}__new"]
+    kw = dict(update_freq=100.0, measurement_freq=10.0, measurement_delay=0.050, dynamic_meas_delay=0,
+              limit_measurement_freq=1, corner_margin_enbl=1, direct_orien_method=1, est_bias=1, multirate_ekf=int(mode == "multirate"))
+    B = 3
+    ekf = qla.BatchedRelativePoseEKF(B, dtype, **kw)
+    ekf.enable_gating(True)
+    rep = lambda a: np.repeat(np.asarray(a)[None], B, 0)
+    ekf.initialize_state(rep(Z[0]), reinit_bias=True)   # the twin initialises on its first detection (tick 0)
+    pending = np.ones(B, np.uint8); zlast = rep(Z[0])
+    tol = 1e-8 if dtype == "f64" else 3e-3
+    for t in range(U.shape[0]):
+        if NEW[t]:
+            zlast = rep(Z[t]); pending[:] = 1
+        ekf.filter_update(rep(U[t]), zlast if pending.any() else None, pending if pending.any() else None, t_curr=0.01 * t,
+                          apriltag_time=np.full(B, 0.01 * t))
+        perf, cons, upds = ekf.tick_flags()
+        pending &= (1 - cons)
+        assert (upds == d[f"{mode}__upds"][t]).all(), t
+        assert (pending == d[f"{mode}__ready"][t]).all(), t
+        x, P = ekf.get_state()
+        xr = d[f"{mode}__x_seq"][t]
+        assert quat_err(x[:, 6:10], rep(xr[6:10])) < tol, t
+        keep = [i for i in range(16) if not 6 <= i < 10]
+        np.testing.assert_allclose(x[:, keep], rep(xr[keep]), rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.einsum("bii->bi", P), rep(d[f"{mode}__P_diag_seq"][t]), rtol=tol * 10)
+    ekf.close()

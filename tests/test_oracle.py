@@ -279,3 +279,36 @@ def test_filter_update_single_rate_matches_manual_loop(golden_dir):
         assert f.f.performed_correction == int(M[t])
         np.testing.assert_allclose(f.x(), d[f"{ps}__x_seq"][t], rtol=1e-9, atol=1e-10)
     np.testing.assert_allclose(np.diag(f.P()), d[f"{ps}__P_diag_seq"][-1], rtol=1e-9)
+
+
+TWIN_FU = dict(update_freq=100.0, measurement_freq=10.0, measurement_delay=0.050, dynamic_meas_delay=0,
+               limit_measurement_freq=1, corner_margin_enbl=1, direct_orien_method=1, est_bias=1)
+
+
+@pytest.mark.parametrize("mode", ["multirate", "singlerate"])
+def test_full_filter_update_against_reference_twin(golden_dir, mode):
+    """The oracle's filter object (EKF.cpp:127-303: rate limit, corner gate, multirate replay with the
+    fixed step delay, counters) against the sequence the reference's own Python twin produced."""
+    d = np.load(os.path.join(golden_dir, "filter_update_cases.npz"))
+    U, Z, NEW = d[f"{mode}__u"], d[f"{mode}__z"], d[f"{mode}__new"]
+    p = oracle.make_params(multirate_ekf=int(mode == "multirate"), **TWIN_FU)
+    assert p.upd_per_meas == 10 and p.measurement_step_delay == 5
+    f = oracle.Filter(p)
+    n_corr = 0
+    for t in range(U.shape[0]):
+        f.set_imu(U[t, :3], U[t, 3:])
+        if NEW[t]:
+            f.set_apriltag(Z[t, :3], Z[t, 3:], 0.01 * t)
+        f.filter_update(0.01 * t)
+        assert f.f.upds_since_correction == d[f"{mode}__upds"][t], t
+        assert f.f.measurement_ready == d[f"{mode}__ready"][t], t
+        if mode == "multirate":
+            assert f.f.hist_len == d[f"{mode}__hist_len"][t], t
+        n_corr += f.f.performed_correction
+        x = f.x()
+        xr = d[f"{mode}__x_seq"][t]
+        assert qclose(x[6:10], xr[6:10], 1e-9)
+        np.testing.assert_allclose(np.delete(x, range(6, 10)), np.delete(xr, range(6, 10)), rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(np.diag(f.P()), d[f"{mode}__P_diag_seq"][t], rtol=1e-8)
+    assert n_corr >= 10
+    np.testing.assert_allclose(f.P(), d[f"{mode}__P_final"], rtol=1e-7, atol=1e-11)
