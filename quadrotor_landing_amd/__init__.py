@@ -2,4 +2,5 @@
 mbrymer/quadrotor_landing's quad_state_estimation filter core)."""
 from ._lib import LIB_PATH, QLE_F32, QLE_F64, QleDerived, QleError, QleParams, QleSynthCfg, lib  # noqa: F401
 from .ekf import BatchedRelativePoseEKF, InputSequence  # noqa: F401
+from .twin import RelativePoseEKF  # noqa: F401
 from .params import default_params, derive, load_yaml, make_params, set_fields  # noqa: F401

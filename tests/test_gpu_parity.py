@@ -675,3 +675,32 @@ def test_full_filter_update_against_reference_twin_golden(mode, dtype):
         np.testing.assert_allclose(x[:, keep], rep(xr[keep]), rtol=tol, atol=tol)
         np.testing.assert_allclose(np.einsum("bii->bi", P), rep(d[f"{mode}__P_diag_seq"][t]), rtol=tol * 10)
     ekf.close()
+
+
+# ------------------------------ the twin's own interface, the twin's own numbers
+def test_twin_interface_reproduces_twin_goldens():
+    """quadrotor_landing_amd.RelativePoseEKF has the Python twin's constructor and step signatures
+    (PYEKF.py:29,373,428); driven exactly as tests/golden/make_golden.py drives the reference twin, it
+    returns the numbers the reference twin returned."""
+    import json
+    kat = json.load(open(f"{GOLDEN}/kat.json"))["appendix_c"]
+    f = qla.RelativePoseEKF(100, 10)
+    x0 = np.array(kat["x"]).reshape(16, 1); u0 = np.array(kat["u"]).reshape(6, 1); P0 = np.diag(kat["P_diag"])
+    xc, Pc, acc = f.prediction_step(x0, u0, P0)
+    assert xc.shape == (16, 1) and Pc.shape == (15, 15) and acc.shape == (3, 1)
+    np.testing.assert_allclose(xc.flatten(), kat["x_check"], rtol=0, atol=1e-15)
+    np.testing.assert_allclose(Pc, kat["P_check"], rtol=1e-12, atol=1e-17)
+    np.testing.assert_allclose(acc.flatten(), kat["accel"], atol=1e-14)
+    xh, Ph = f.correction_step(xc, Pc, np.array(kat["r_c_tc"]).reshape(3, 1), np.array(kat["q_ct_xyzw"]))
+    np.testing.assert_allclose(xh.flatten(), kat["x_hat"], rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Ph, kat["P_hat"], rtol=1e-10, atol=1e-15)
+    # the 9-state variant through the same attribute the twin uses
+    d = np.load(f"{GOLDEN}/predict_cases.npz")
+    f.est_bias = False
+    f.Q = np.diag([0.005] * 3 + [0.0005] * 3)
+    f.sync_params()
+    assert f.num_states == 9
+    xc, Pc, _ = f.prediction_step(d["nobias__x"][5].reshape(16, 1), d["nobias__u"][5].reshape(6, 1), d["nobias__P"][5])
+    np.testing.assert_allclose(xc.flatten(), d["nobias__x_check"][5], atol=1e-13)
+    np.testing.assert_allclose(Pc, d["nobias__P_check"][5], rtol=1e-11, atol=1e-15)
+    f.close()
