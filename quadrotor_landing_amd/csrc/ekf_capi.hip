@@ -46,6 +46,14 @@ static int fail(int code, const char* fmt, ...)
         if (rc_ != QLE_OK) return rc_; \
     } while (0)
 
+// Nothing may throw across the C ABI: entry points that allocate host memory run under this guard.
+#define QLE_GUARD_BEGIN try {
+#define QLE_GUARD_END                                                                   \
+    }                                                                                   \
+    catch (const std::bad_alloc&) { return fail(QLE_ERR_NOMEM, "host allocation failed"); } \
+    catch (const std::exception& e_) { return fail(QLE_ERR_INVALID, "unexpected exception: %s", e_.what()); } \
+    catch (...) { return fail(QLE_ERR_INVALID, "unexpected exception"); }
+
 extern "C" const char* qle_last_error(void) { return g_err.c_str(); }
 extern "C" const char* qle_version(void) { return "quadrotor_landing_amd 0.1 (gfx950)"; }
 
@@ -522,7 +530,9 @@ extern "C" int qle_get_aux(qle_batch* h, double* accel_rel, double* obs)
 {
     QLE_TRY(check_handle(h));
     if (!h->aux_accel) return fail(QLE_ERR_STATE, "aux outputs are not enabled (qle_enable_aux)");
+    QLE_GUARD_BEGIN
     return BY_DTYPE(h, get_aux_t, h, accel_rel, obs);
+    QLE_GUARD_END
 }
 
 // -------------------------------------------------------------- hot launches
@@ -787,6 +797,7 @@ extern "C" int qle_get_tick_flags(qle_batch* h, uint8_t* performed_correction, u
 {
     QLE_TRY(check_handle(h));
     if (!h->last_corr) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
+    QLE_GUARD_BEGIN
     std::vector<uint8_t> f((size_t)h->B);
     std::vector<int32_t> lc((size_t)h->B);
     HIP_TRY(hipMemcpyAsync(f.data(), h->flags, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
@@ -798,6 +809,7 @@ extern "C" int qle_get_tick_flags(qle_batch* h, uint8_t* performed_correction, u
         if (upds_since_correction) upds_since_correction[i] = (int32_t)(h->tick - 1 - lc[(size_t)i]);  // EKF.cpp:292-299
     }
     return QLE_OK;
+    QLE_GUARD_END
 }
 
 template <typename T>
@@ -893,7 +905,12 @@ extern "C" int qle_inputs_create(qle_batch* h, int64_t n_ticks, const uint8_t* t
     in->h = h;
     in->device = h->device;
     in->T = n_ticks;
-    in->slot.assign((size_t)n_ticks, -1);
+    try {
+        in->slot.assign((size_t)n_ticks, -1);
+    } catch (...) {
+        delete in;
+        return fail(QLE_ERR_NOMEM, "host allocation of the slot table for %lld ticks failed", (long long)n_ticks);
+    }
     for (int64_t t = 0; t < n_ticks; ++t)
         if (tick_has_meas && tick_has_meas[t]) in->slot[(size_t)t] = (int32_t)in->n_slots++;
     in->pitch_u = align_up(kUW * (size_t)h->Bp * h->wsz, 256);
