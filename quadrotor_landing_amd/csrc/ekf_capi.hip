@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "ekf_kernels.hpp"
+#include "ekf_rows.hpp"
 #include "synth_kernels.hpp"
 
 using namespace qle;
@@ -145,6 +146,8 @@ struct qle_batch {
     int32_t device = 0;
     int32_t block = 256;
     int32_t nt = 0;        // cache policy of the hot kernels' streaming accesses (0 default, 2 non-temporal)
+    int64_t rows_max = 0;  // batches up to this size may use the rows-across-lanes kernel (ekf_rows.hpp)
+    bool rows_forced = false;  // QLE_ROWS_MAX set: use it for every eligible tick (tests, experiments)
     size_t wsz = 4;
     qle_params pub;
     qle_derived der;
@@ -334,6 +337,11 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         h->nt = (state_mib <= 38.0 || state_mib >= 300.0) ? 2 : 0;
         if (const char* s = std::getenv("QLE_NT")) h->nt = std::atoi(s) >= 1 ? 2 : 0;
     }
+    // Rows-across-lanes kernel (16 lanes per filter).  Measured (profiles/r01_tuning.md section 3): its per-wave
+    // instruction stream is as long as the one-lane-per-filter kernels', so it only pays where those spill:
+    // fp64 ticks that carry corrections, up to ~6k filters (BASELINE cfg 2: 15 vs 23 us per tick).
+    h->rows_max = dtype == QLE_F64 ? 6144 : 0;
+    if (const char* s = std::getenv("QLE_ROWS_MAX")) { h->rows_max = std::atoll(s); h->rows_forced = true; }
     if (const char* s = std::getenv("QLE_BLOCK")) {
         int b = std::atoi(s);
         if (b == 64 || b == 128 || b == 256) h->block = b;
@@ -547,6 +555,28 @@ static int mr_prepare(qle_batch* h)
     return QLE_OK;
 }
 
+// The rows-across-lanes kernel covers the plain single-rate tick (no device gating, no multirate history,
+// no side outputs); everything else runs on the one-lane-per-filter kernels.
+static inline bool use_rows(const qle_batch* h, bool has_meas)
+{
+    return h->B <= h->rows_max && (has_meas || h->rows_forced) && !h->mr && !h->gating && !h->aux;
+}
+
+template <typename T>
+static int launch_rows(qle_batch* h, const void* u, const void* z)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const int64_t lanes = h->B * kRowLanes;
+    const dim3 g((unsigned)((lanes + kBlock - 1) / kBlock)), b(kBlock);
+    const T* pfp = (const T*)h->pfp;
+#define QLE_ROWS(D, F) hipLaunchKernelGGL((k_rows<T, D, F>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)u, (const T*)z, pfp, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_ROWS(true, true); else QLE_ROWS(true, false); }
+    else { if (h->pfp_on) QLE_ROWS(false, true); else QLE_ROWS(false, false); }
+#undef QLE_ROWS
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+
 // prediction_step from `src` into `dst`; keep_u: the record also stores the IMU sample (multirate history).
 template <typename T>
 static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u)
@@ -571,6 +601,7 @@ static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void*
 template <typename T>
 static int launch_predict(qle_batch* h, const void* u)
 {
+    if (use_rows(h, false)) return launch_rows<T>(h, u, nullptr);
     QLE_TRY(mr_prepare(h));
     return launch_predict_sd<T>(h, u, state_cur(h), state_next(h), h->mr);
 }
@@ -652,6 +683,7 @@ static int launch_step_mr(qle_batch* h, const void* u, const void* z)
 template <typename T>
 static int launch_step(qle_batch* h, const void* u, const void* z)
 {
+    if (use_rows(h, true)) return launch_rows<T>(h, u, z);
     if (h->mr) return launch_step_mr<T>(h, u, z);
     if (h->pub.direct_orien_method) return h->gating ? launch_step_dg<T, true, true>(h, u, z) : launch_step_dg<T, true, false>(h, u, z);
     return h->gating ? launch_step_dg<T, false, true>(h, u, z) : launch_step_dg<T, false, false>(h, u, z);

@@ -23,6 +23,21 @@ from util import (GOLDEN, assert_state_close, golden_kwargs, meas_near, oracle_p
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["default", "rows-forced", "lanes-only"])
+def kernel_family(request, monkeypatch):
+    """Two kernel families implement the plain single-rate tick: one lane per filter (ekf_kernels.hpp) and
+    rows across lanes (16 lanes per filter, ekf_rows.hpp; by default only for small fp64 batches).  Every test
+    runs with the default policy, with the rows kernel forced wherever it is eligible, and with it disabled,
+    so both families are checked against the oracle in both dtypes (QLE_ROWS_MAX is read at handle creation)."""
+    if request.param == "lanes-only":
+        monkeypatch.setenv("QLE_ROWS_MAX", "0")
+    elif request.param == "rows-forced":
+        monkeypatch.setenv("QLE_ROWS_MAX", str(1 << 40))
+    else:
+        monkeypatch.delenv("QLE_ROWS_MAX", raising=False)
+    return request.param
+
 F64 = dict(rtol=1e-12, atol=1e-14, qtol=1e-11)
 F32 = dict(rtol=2e-5, atol=2e-6, qtol=2e-6)
 
