@@ -11,6 +11,10 @@
 //
 //   ekf_driver --config relative_pose_EKF_rotors.yaml --batch 65536 --ticks 1000 [--dtype f32|f64]
 //              [--device 0] [--seed N] [--update-freq HZ] [--measurement-freq HZ] [--corner-gate 0|1] [--multirate 0|1]
+//              [--devices N]   shard the batch over N devices in this process: one handle + one HIP stream per
+//                              device, one host thread each, no collective; the three RMSE sums and the reports
+//                              are combined on the host.  Shards wrap onto the devices
+//                              that exist, so N > #GPUs is a functional rehearsal.
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -20,6 +24,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/qle_ekf.h"
@@ -89,7 +94,7 @@ int main(int argc, char** argv)
     int dtype = QLE_F32, device = 0;
     uint64_t seed = 0xE4F00001ULL;
     double update_freq = 0, measurement_freq = 0;
-    int corner_gate = -1, multirate = -1;
+    int corner_gate = -1, multirate = -1, n_devices = 1;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return std::string(argv[++i]); };
@@ -103,6 +108,7 @@ int main(int argc, char** argv)
         else if (a == "--measurement-freq") measurement_freq = std::atof(next().c_str());
         else if (a == "--corner-gate") corner_gate = std::atoi(next().c_str());
         else if (a == "--multirate") multirate = std::atoi(next().c_str());
+        else if (a == "--devices") n_devices = std::max(1, std::atoi(next().c_str()));
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
 
@@ -145,61 +151,109 @@ int main(int argc, char** argv)
     qle_derived d;
     check(qle_params_derive(&p, &d), "qle_params_derive");
 
-    qle_batch* h = nullptr;
-    check(qle_create(&h, batch, dtype, device, &p), "qle_create");
-    check(qle_enable_gating(h, 1), "qle_enable_gating");
-    // a tag pose arrives every upd_per_meas ticks (the detector runs at measurement_freq)
-    std::vector<uint8_t> has((size_t)ticks, 0);
-    for (int64_t t = d.upd_per_meas - 1; t < ticks; t += d.upd_per_meas) has[(size_t)t] = 1;
-    qle_inputs* in = nullptr;
-    check(qle_inputs_create(h, ticks, has.data(), &in), "qle_inputs_create");
-    qle_synth_cfg sc;
-    check(qle_synth_cfg_default(&sc), "qle_synth_cfg_default");
-    sc.seed = seed;
-    if (p.multirate_ekf) {
-        // camera latency of the synthetic source = the configured measurement_delay (EKF.cpp:93,199):
-        // a tag pose delivered at tick t shows the pose `measurement_step_delay` ticks back.
-        sc.meas_delay_ticks = d.measurement_step_delay;
-        check(qle_set_uniform_measurement_age(h, p.dynamic_meas_delay ? d.measurement_step_delay * d.dT_nom - p.dyn_measurement_delay_offset
-                                                                       : p.measurement_delay), "qle_set_uniform_measurement_age");
+    // ---- shards: contiguous ranges of the global filter index, one per device
+    int32_t ndev_avail = 0;
+    check(qle_device_count(&ndev_avail), "qle_device_count");
+    struct Shard {
+        int dev = 0;
+        int64_t lo = 0, n = 0;
+        float ms = 0;
+        double rm[3] = {0, 0, 0};
+        int64_t bad = 0, tracked = 0;
+        std::vector<double> pose, cov, vel, bias;
+        std::vector<int32_t> upds;
+        std::string err;
+    };
+    std::vector<Shard> shards((size_t)n_devices);
+    {
+        const int64_t base = batch / n_devices, extra = batch % n_devices;
+        int64_t lo = 0;
+        for (int k = 0; k < n_devices; ++k) {
+            shards[(size_t)k].dev = (device + k) % std::max<int32_t>(ndev_avail, 1);
+            shards[(size_t)k].lo = lo;
+            shards[(size_t)k].n = base + (k < extra ? 1 : 0);
+            lo += shards[(size_t)k].n;
+        }
     }
-    check(qle_synth_generate(h, in, &sc), "qle_synth_generate");
-
-    check(qle_synchronize(h), "qle_synchronize");
+    std::vector<uint8_t> has((size_t)ticks, 0);
+    for (int64_t t = d.upd_per_meas - 1; t < ticks; t += d.upd_per_meas) has[(size_t)t] = 1;  // a tag pose every upd_per_meas ticks
+    auto run_shard = [&](Shard& sh) {
+        // errors are thread-local in the library: report them through the shard
+        auto ok = [&](int rc, const char* what) {
+            if (rc != QLE_OK && sh.err.empty()) sh.err = std::string(what) + ": " + qle_last_error();
+            return rc == QLE_OK;
+        };
+        qle_batch* h = nullptr;
+        qle_inputs* in = nullptr;
+        if (sh.n == 0) return;
+        do {
+            if (!ok(qle_create(&h, sh.n, dtype, sh.dev, &p), "qle_create")) break;
+            if (!ok(qle_enable_gating(h, 1), "qle_enable_gating")) break;
+            if (!ok(qle_inputs_create(h, ticks, has.data(), &in), "qle_inputs_create")) break;
+            qle_synth_cfg sc;
+            qle_synth_cfg_default(&sc);
+            sc.seed = seed;
+            sc.filter_offset = sh.lo;  // data depend on the GLOBAL filter index only
+            if (p.multirate_ekf) {
+                // camera latency of the synthetic source = the configured measurement_delay (EKF.cpp:93,199)
+                sc.meas_delay_ticks = d.measurement_step_delay;
+                if (!ok(qle_set_uniform_measurement_age(h, p.dynamic_meas_delay ? d.measurement_step_delay * d.dT_nom - p.dyn_measurement_delay_offset
+                                                                                   : p.measurement_delay), "qle_set_uniform_measurement_age")) break;
+            }
+            if (!ok(qle_synth_generate(h, in, &sc), "qle_synth_generate")) break;
+            if (!ok(qle_synchronize(h), "qle_synchronize")) break;
+            if (!ok(qle_timer_begin(h), "qle_timer_begin")) break;
+            if (!ok(qle_run(h, in, 0, ticks), "qle_run")) break;
+            if (!ok(qle_timer_end(h, &sh.ms), "qle_timer_end")) break;
+            sh.pose.resize((size_t)sh.n * 7); sh.cov.resize((size_t)sh.n * 36); sh.vel.resize((size_t)sh.n * 3); sh.bias.resize((size_t)sh.n * 6);
+            if (!ok(qle_get_report(h, sh.pose.data(), sh.cov.data(), sh.vel.data(), sh.bias.data()), "qle_get_report")) break;
+            std::vector<uint8_t> perf((size_t)sh.n), cons((size_t)sh.n);
+            sh.upds.resize((size_t)sh.n);
+            if (!ok(qle_get_tick_flags(h, perf.data(), cons.data(), sh.upds.data()), "qle_get_tick_flags")) break;
+            if (!ok(qle_synth_rmse(h, in, sh.rm), "qle_synth_rmse")) break;
+            if (!ok(qle_count_nonfinite(h, &sh.bad), "qle_count_nonfinite")) break;
+            for (int64_t i = 0; i < sh.n; ++i) sh.tracked += sh.upds[(size_t)i] < 2 * d.upd_per_meas ? 1 : 0;
+        } while (false);
+        qle_inputs_destroy(in);
+        qle_destroy(h);
+    };
     auto t0 = std::chrono::steady_clock::now();
-    check(qle_timer_begin(h), "qle_timer_begin");
-    check(qle_run(h, in, 0, ticks), "qle_run");
-    float ms = 0;
-    check(qle_timer_end(h, &ms), "qle_timer_end");
+    if (n_devices == 1) {
+        run_shard(shards[0]);
+    } else {
+        std::vector<std::thread> th;
+        for (auto& sh : shards) th.emplace_back(run_shard, std::ref(sh));
+        for (auto& t : th) t.join();
+    }
     double wall = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-
-    std::vector<double> pose((size_t)batch * 7), cov((size_t)batch * 36), vel((size_t)batch * 3), bias((size_t)batch * 6);
-    check(qle_get_report(h, pose.data(), cov.data(), vel.data(), bias.data()), "qle_get_report");
-    std::vector<uint8_t> perf((size_t)batch), cons((size_t)batch);
-    std::vector<int32_t> upds((size_t)batch);
-    check(qle_get_tick_flags(h, perf.data(), cons.data(), upds.data()), "qle_get_tick_flags");
-    double rm[3];
-    check(qle_synth_rmse(h, in, rm), "qle_synth_rmse");
-    int64_t bad = 0;
-    check(qle_count_nonfinite(h, &bad), "qle_count_nonfinite");
+    for (auto& sh : shards)
+        if (!sh.err.empty()) { std::fprintf(stderr, "shard on device %d failed: %s\n", sh.dev, sh.err.c_str()); return 1; }
+    // host-side combination: max of the device times, sums of the three RMSE scalars, filter 0's report
+    float ms = 0;
+    double rm[3] = {0, 0, 0};
+    int64_t bad = 0, tracked = 0;
+    for (auto& sh : shards) {
+        ms = std::max(ms, sh.ms);
+        for (int k = 0; k < 3; ++k) rm[k] += sh.rm[k];
+        bad += sh.bad; tracked += sh.tracked;
+    }
+    const std::vector<double>&pose = shards[0].pose, &cov = shards[0].cov, &vel = shards[0].vel, &bias = shards[0].bias;
+    const std::vector<int32_t>& upds = shards[0].upds;
 
     std::printf("%s\n", qle_version());
     std::printf("params: update_freq %.1f Hz, measurement_freq %.1f Hz (every %d ticks), num_states %d, direct_orien_method %d, limit %d, corner gate %d, n_tags %d, multirate %d (step delay %d)\n",
                 p.update_freq, p.measurement_freq, d.upd_per_meas, d.num_states, p.direct_orien_method, p.limit_measurement_freq, p.corner_margin_enbl, p.n_tags,
                 p.multirate_ekf, d.measurement_step_delay);
-    std::printf("batch %lld x %lld ticks (%s): %.3f ms device, %.3f ms wall -> %.3e ticks/s\n", (long long)batch, (long long)ticks,
-                dtype == QLE_F32 ? "fp32" : "fp64", ms, wall * 1e3, (double)batch * ticks / (ms * 1e-3));
+    std::printf("batch %lld x %lld ticks (%s) on %d device shard(s) [%d device(s) present]: %.3f ms device (max over shards), %.3f ms wall incl. setup -> %.3e ticks/s\n",
+                (long long)batch, (long long)ticks, dtype == QLE_F32 ? "fp32" : "fp64", n_devices, (int)ndev_avail, ms, wall * 1e3,
+                (double)batch * ticks / (ms * 1e-3));
     std::printf("filter 0: rel_pose position (%.4f, %.4f, %.4f) orientation xyzw (%.4f, %.4f, %.4f, %.4f)\n", pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
     std::printf("filter 0: velocity (%.4f, %.4f, %.4f)  IMU bias+static accel (%.4f, %.4f, %.4f) gyro (%.5f, %.5f, %.5f)\n", vel[0], vel[1], vel[2], bias[0], bias[1],
                 bias[2], bias[3], bias[4], bias[5]);
     std::printf("filter 0: pose covariance diag (%.3e, %.3e, %.3e, %.3e, %.3e, %.3e)  upds_since_correction %d\n", cov[0], cov[7], cov[14], cov[21], cov[28], cov[35], upds[0]);
-    int64_t tracked = 0;
-    for (int64_t i = 0; i < batch; ++i) tracked += upds[(size_t)i] < 2 * d.upd_per_meas ? 1 : 0;
     std::printf("filters corrected within the last %d ticks: %lld of %lld (the corner gate, EKF.cpp:156-186, rejects tags outside the image margins)\n",
                 2 * d.upd_per_meas, (long long)tracked, (long long)batch);
     std::printf("RMSE vs synthetic truth over %.0f filters: position %.4f m, attitude %.4f rad; non-finite filters: %lld\n", rm[2], std::sqrt(rm[0] / rm[2]),
                 std::sqrt(rm[1] / rm[2]), (long long)bad);
-    qle_inputs_destroy(in);
-    qle_destroy(h);
     return bad == 0 ? 0 : 3;
 }
