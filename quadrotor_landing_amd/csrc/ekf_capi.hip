@@ -176,7 +176,9 @@ struct qle_batch {
     bool gating = false;
     int32_t* last_corr = nullptr;  // [B] index of each filter's last correcting tick, -1 = never
     uint8_t* flags = nullptr;      // [B] bit0 performed_correction, bit1 measurement consumed (last measurement tick)
-    int64_t tick = 0;              // filter_update ticks executed so far
+    int64_t tick = 0;              // filter_update ticks executed so far (since the last origin shift)
+    int64_t tick_origin = 0;       // ticks removed by origin shifts (reporting only)
+    int64_t rebase_at = (int64_t)1 << 30;  // shift the tick origin when the counter reaches this (QLE_TICK_REBASE for tests)
     // multirate EKF (EKF.cpp:196-236, 251-264)
     bool mr = false;               // pub.multirate_ekf
     bool hist_dirty = true;        // state was overwritten: restart the history at the next tick
@@ -342,6 +344,10 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // fp64 ticks that carry corrections, up to ~6k filters (BASELINE cfg 2: 15 vs 23 us per tick).
     h->rows_max = dtype == QLE_F64 ? 6144 : 0;
     if (const char* s = std::getenv("QLE_ROWS_MAX")) { h->rows_max = std::atoll(s); h->rows_forced = true; }
+    if (const char* s = std::getenv("QLE_TICK_REBASE")) {
+        const long long v = std::atoll(s);
+        if (v >= 16) h->rebase_at = v;
+    }
     if (const char* s = std::getenv("QLE_BLOCK")) {
         int b = std::atoi(s);
         if (b == 64 || b == 128 || b == 256) h->block = b;
@@ -713,9 +719,10 @@ static int launch_update(qle_batch* h, const void* z)
 static int advance_tick(qle_batch* h)
 {
     h->tick++;
-    if (h->tick >= (int64_t)1 << 30) {
+    if (h->tick >= h->rebase_at) {
         const int64_t C = h->C > 0 ? h->C : 1;
-        const int64_t shift = (((int64_t)1 << 29) / C) * C;
+        const int64_t shift = ((h->rebase_at / 2) / C) * C;  // a multiple of C: ring slots (tick % C) are unchanged
+        if (shift <= 0) return QLE_OK;
         int32_t* arrs[2] = {h->last_corr, h->hist_first};
         for (int32_t* a : arrs)
             if (a) {
@@ -723,6 +730,7 @@ static int advance_tick(qle_batch* h)
                 HIP_TRY(hipGetLastError());
             }
         h->tick -= shift;
+        h->tick_origin += shift;
     }
     return QLE_OK;
 }

@@ -494,6 +494,8 @@ __global__ void k_rebase_ticks(int32_t* __restrict__ last_corr, int32_t shift, i
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
+    // saturate far in the past: such a filter has not corrected / has no history entry for longer than any
+    // rate limit or ring capacity, which is all the consumers of these indices distinguish
     const int64_t v = (int64_t)last_corr[i] - shift;
     last_corr[i] = (int32_t)(v < -(int64_t)(1 << 30) ? -(int64_t)(1 << 30) : v);
 }

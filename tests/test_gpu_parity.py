@@ -719,3 +719,14 @@ def test_twin_interface_reproduces_twin_goldens():
     np.testing.assert_allclose(xc.flatten(), d["nobias__x_check"][5], atol=1e-13)
     np.testing.assert_allclose(Pc, d["nobias__P_check"][5], rtol=1e-11, atol=1e-15)
     f.close()
+
+
+def test_tick_origin_shift_is_invisible(monkeypatch):
+    """Tick indices are 32-bit on the device (last_corr, hist_first, ring slot = tick % C); the host shifts the
+    origin long before they could wrap.  With the threshold lowered to 48 ticks the gating and multirate parity
+    tests cross several shifts and must still match the oracle tick for tick."""
+    monkeypatch.setenv("QLE_TICK_REBASE", "48")
+    test_filter_update_gating_matches_reference_logic(dict(limit_measurement_freq=1, measurement_freq=30.0, corner_margin_enbl=1), "f64")
+    test_multirate_replay_matches_reference_logic(dict(dynamic_meas_delay=1, measurement_delay=0.030, measurement_delay_max=0.200,
+                                                       dyn_measurement_delay_offset=0.005, limit_measurement_freq=1, measurement_freq=15.0), "f64")
+    test_full_filter_update_against_reference_twin_golden("multirate", "f64")
