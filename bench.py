@@ -249,7 +249,7 @@ def main():
     if resident is not None:
         out["on_chip_resident"] = resident
     if x0 is not None:
-        out["cpu_baseline"] = cpu_baseline(seq, x0, P0, min(B, 65536), 140)
+        out["cpu_baseline"] = cpu_baseline(seq, x0, P0, min(B, 65536), min(140, T))
     if rank == 0:
         print(json.dumps(out), flush=True)
     ekf.close()
