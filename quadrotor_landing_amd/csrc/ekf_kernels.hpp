@@ -8,7 +8,7 @@
 //     off(word w, filter i) = (i/64)*WT*64 + ((w/VW)*64 + i%64)*VW + w%VW
 // Lane l of a wave reads one aligned 16-byte quad per row (global_load_dwordx4),
 // a row is 1 KiB contiguous, and the whole record of a wave is one contiguous
-// block (state: 136 words -> 34 KiB fp32 / 68 KiB fp64 per tile), so a wave
+// block (state: 144 words -> 36 KiB fp32 / 72 KiB fp64 per tile), so a wave
 // touches a handful of DRAM pages / TLB entries instead of one per row.
 // A record whose length is not a multiple of VW (fp32 u: 6 words) ends in one
 // row of 8-byte halves.
