@@ -63,7 +63,7 @@ extern "C" int qle_device_count(int32_t* count)
     if (!count) return fail(QLE_ERR_INVALID, "count is null");
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess) { *count = 0; return fail(QLE_ERR_NO_DEVICE, "hipGetDeviceCount: %s", hipGetErrorString(e)); }
+    if (e != hipSuccess) { *count = 0; return fail(QLE_ERR_NO_DEVICE, "no HIP device available (%s); this engine has no CPU fallback", hipGetErrorString(e)); }
     *count = n;
     return QLE_OK;
 }

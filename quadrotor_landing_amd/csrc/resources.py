@@ -9,7 +9,8 @@ import sys
 here = os.path.dirname(os.path.abspath(__file__))
 src = sys.argv[1] if len(sys.argv) > 1 else "ekf_capi.hip"
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
-cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950",
+cmd = ["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize",
+       "-mllvm", "-amdgpu-sched-strategy=max-memory-clause",
        "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null", src]
 out = subprocess.run(cmd, cwd=here, capture_output=True, text=True).stderr
 rows, cur = [], {}
