@@ -11,6 +11,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = os.path.join(_HERE, "libekf_oracle.so")
+_LIB_STRUCT = os.path.join(_HERE, "libekf_oracle_structured.so")
 ORC_MAX_TAGS = 16
 
 _d = C.c_double
@@ -63,6 +64,42 @@ def build(force=False):
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B", "libekf_oracle.so"], check=True)
     return _LIB
+
+
+def build_structured(force=False):
+    src = [os.path.join(_HERE, "ekf_structured_cpu.cpp"), os.path.join(_HERE, "..", "quadrotor_landing_amd", "csrc", "ekf_device.hpp")]
+    stale = (not os.path.exists(_LIB_STRUCT)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_STRUCT) for s in src)
+    if force or stale:
+        subprocess.run(["make", "-C", _HERE, "-s", "-B", "libekf_oracle_structured.so"], check=True)
+    return _LIB_STRUCT
+
+
+_slib = None
+
+
+def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True, n_threads=0):
+    """The engine's own per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_device.hpp) compiled for the CPU:
+    same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product."""
+    global _slib
+    if _slib is None:
+        build_structured()
+        _slib = C.CDLL(_LIB_STRUCT)
+        _slib.orc_structured_run_batch.argtypes = [C.POINTER(OrcParams), C.c_int64, C.c_int64, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
+                                                   C.POINTER(_d), C.POINTER(C.c_uint8), _i, _i, _i]
+        _slib.orc_structured_run_batch.restype = C.c_int64
+    n = p.num_states
+    x = np.array(x, dtype=np.float64, order="C").reshape(-1, 16)
+    B = x.shape[0]
+    P = np.array(P, dtype=np.float64, order="C").reshape(B, n * n)
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, B, 6)
+    T = u.shape[0]
+    zp = mp = None
+    if mask is not None:
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(T, B, 7)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(T, B)
+        zp = _p(z); mp = mask.ctypes.data_as(C.POINTER(C.c_uint8))
+    _slib.orc_structured_run_batch(C.byref(p), B, T, _p(x), _p(P), _p(u), zp, mp, 0 if dtype == "f32" else 1, int(bool(levels)), int(n_threads))
+    return x, P.reshape(B, n, n)
 
 
 _lib = None

@@ -20,7 +20,7 @@ def pytest_sessionstart(session):
     import subprocess
     if not os.path.exists(os.path.join(ROOT, "quadrotor_landing_amd", "libqle_ekf.so")):
         subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc")], check=True)
-    if not os.path.exists(os.path.join(ROOT, "oracle", "libekf_oracle.so")):
+    if not (os.path.exists(os.path.join(ROOT, "oracle", "libekf_oracle.so")) and os.path.exists(os.path.join(ROOT, "oracle", "libekf_oracle_structured.so"))):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle")], check=True)
 
 

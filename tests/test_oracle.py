@@ -312,3 +312,49 @@ def test_full_filter_update_against_reference_twin(golden_dir, mode):
         np.testing.assert_allclose(np.diag(f.P()), d[f"{mode}__P_diag_seq"][t], rtol=1e-8)
     assert n_corr >= 10
     np.testing.assert_allclose(f.P(), d[f"{mode}__P_final"], rtol=1e-7, atol=1e-11)
+
+
+# ---------------- the engine's block-structured algebra, compiled for the CPU, against the dense oracle
+@pytest.mark.parametrize("levels", [True, False])
+@pytest.mark.parametrize("direct", [0, 1])
+@pytest.mark.parametrize("est_bias", [0, 1])
+def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, est_bias, levels):
+    """oracle/ekf_structured_cpu.cpp compiles quadrotor_landing_amd/csrc/ekf_device.hpp for the host: the same
+    F = L3 L2 L1 congruences / levelled predict and decorrelated sequential update the HIP kernels run, checked
+    here (no GPU) against the dense reference-shaped restatement over a 60-tick sequence."""
+    rng = np.random.default_rng(40 + 2 * direct + est_bias)
+    p = oracle.make_params(direct_orien_method=direct, est_bias=est_bias, update_freq=400.0, ab_static=[0.2, -0.09, -0.03],
+                           wb_static=[-0.02, -0.01, 0.0], q_vc=[-0.7035177, 0.7106742, 0.0014521, -0.0017207],
+                           r_v_cv=[0.06036412, -0.00145196, -0.04439579])
+    pn = ekf_np.Params.from_orc(p)
+    n = p.num_states
+    B, T = 24, 60
+    x = np.stack([rand_case(rng, n)[0] for _ in range(B)]); P = np.stack([rand_case(rng, n)[1] for _ in range(B)])
+    U = rng.normal(size=(T, B, 6)) * np.array([1.5, 1.5, 1.5, 0.4, 0.4, 0.4]) + np.array([0, 0, 9.8, 0, 0, 0])
+    M = np.zeros((T, B), np.uint8); M[4::5] = 1
+    Z = np.zeros((T, B, 7)); Z[..., 6] = 1
+    xr, Pr = x.copy(), P.copy()
+    # build measurements near the dense oracle's own trajectory so the innovations stay moderate
+    for t in range(T):
+        xr, Pr = oracle.run_batch(p, xr, Pr, U[t][None])
+        if M[t].any():
+            for i in range(B):
+                ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+                dq = np.append(ax * math.sin(0.15), math.cos(0.15))
+                q_true = ekf_np.qmul(xr[i, 6:10], dq); r_true = xr[i, 0:3] + rng.normal(size=3) * 0.05
+                Z[t, i, 3:] = ekf_np.qmul(ekf_np.qconj(pn.q_vc), ekf_np.qconj(q_true))
+                Z[t, i, :3] = pn.C_vc.T @ (-ekf_np.rot(q_true).T @ r_true - pn.r_v_cv)
+            xr2 = xr.copy(); Pr2 = Pr.copy()
+            for i in range(B):
+                xr2[i], Pr2[i] = oracle.correction_step(p, xr[i], Pr[i], Z[t, i, :3], Z[t, i, 3:])[:2]
+            xr, Pr = xr2, Pr2
+    xd, Pd = oracle.run_batch(p, x, P, U, Z, M)
+    np.testing.assert_allclose(xd, xr, rtol=0, atol=0)  # the incremental construction above is the same computation
+    for dtype, tol in (("f64", 1e-10), ("f32", 2e-3)):
+        xs, Ps = oracle.structured_run_batch(p, x, P, U, Z, M, dtype=dtype, levels=levels)
+        dqv = np.minimum(np.abs(xs[:, 6:10] - xd[:, 6:10]).max(1), np.abs(xs[:, 6:10] + xd[:, 6:10]).max(1)).max()
+        assert dqv < tol, (dtype, dqv)
+        keep = [i for i in range(16) if not 6 <= i < 10]
+        np.testing.assert_allclose(xs[:, keep], xd[:, keep], rtol=tol, atol=tol)
+        sc = np.sqrt(np.einsum("bii->bi", Pd)[:, :, None] * np.einsum("bii->bi", Pd)[:, None, :])
+        assert (np.abs(Ps - Pd) / sc).max() < tol * 10, dtype
