@@ -358,3 +358,21 @@ def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, 
         np.testing.assert_allclose(xs[:, keep], xd[:, keep], rtol=tol, atol=tol)
         sc = np.sqrt(np.einsum("bii->bi", Pd)[:, :, None] * np.einsum("bii->bi", Pd)[:, None, :])
         assert (np.abs(Ps - Pd) / sc).max() < tol * 10, dtype
+
+
+@pytest.mark.parametrize("ps", PSETS)
+@pytest.mark.parametrize("levels", [True, False])
+def test_structured_cpu_build_against_reference_twin_sequences(golden_dir, ps, levels):
+    """The engine's arithmetic (CPU build) against the trajectories the reference's Python twin produced."""
+    sets = load_param_sets(golden_dir)
+    d = np.load(os.path.join(golden_dir, "sequence_cases.npz"))
+    p = orc_params_for(ps, sets)
+    U, Z, M = d[f"{ps}__u"], d[f"{ps}__z"], d[f"{ps}__mask"]
+    T = U.shape[0]
+    for dtype, tol in (("f64", 1e-9), ("f32", 3e-3)):
+        x, P = oracle.structured_run_batch(p, d[f"{ps}__x_init"][None], d[f"{ps}__P_init"][None], U[:, None, :], Z[:, None, :], M[:, None],
+                                           dtype=dtype, levels=levels)
+        xr = d[f"{ps}__x_seq"][T - 1]
+        assert qclose(x[0, 6:10], xr[6:10], tol * 10)
+        np.testing.assert_allclose(np.delete(x[0], range(6, 10)), np.delete(xr, range(6, 10)), rtol=tol, atol=tol)
+        np.testing.assert_allclose(np.diag(P[0]), d[f"{ps}__P_diag_seq"][T - 1], rtol=tol * 10)
