@@ -4,3 +4,4 @@ from ._lib import LIB_PATH, QLE_F32, QLE_F64, QleDerived, QleError, QleParams, Q
 from .ekf import BatchedRelativePoseEKF, InputSequence  # noqa: F401
 from .twin import RelativePoseEKF  # noqa: F401
 from .params import default_params, derive, load_yaml, make_params, set_fields  # noqa: F401
+from . import replay  # noqa: F401

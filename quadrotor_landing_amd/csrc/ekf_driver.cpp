@@ -15,6 +15,14 @@
 //                              device, one host thread each, no collective; the three RMSE sums and the reports
 //                              are combined on the host.  Shards wrap onto the devices
 //                              that exist, so N > #GPUs is a functional rehearsal.
+//              [--sequence LOG.csv [--trace OUT.csv]]
+//                              replay a RECORDED event log instead of generating one: the node's three callbacks
+//                              (NODE.cpp:144-182) are driven from the file in time order --
+//                                  imu,<t>,<ax>,<ay>,<az>,<wx>,<wy>,<wz>                       IMUSubCallback
+//                                  tag,<t_arrival>,<header stamp>,<px>,<py>,<pz>,<qx>,<qy>,<qz>,<qw>   AprilTagSubCallback
+//                              and FilterUpdateCallback fires every 1/update_freq s from the first event on.  Every
+//                              filter of the batch sees the same stream; --trace writes what the node would publish
+//                              for filter 0 on every tick (NODE.cpp:192-281).
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -85,12 +93,125 @@ void check(int rc, const char* what)
     if (rc != QLE_OK) { std::fprintf(stderr, "%s failed (%d): %s\n", what, rc, qle_last_error()); std::exit(1); }
 }
 
+// ---- recorded event log: the ROS side of the node, stubbed ----------------------------------------------------
+struct Event {
+    double t = 0;       // arrival time: when the node's callback would run
+    bool tag = false;   // false: IMU sample (v[0..5]); true: tag detection (stamp + v[0..6] = position, orientation xyzw)
+    double stamp = 0;   // AprilTagDetectionArray header stamp (NODE.cpp:167)
+    double v[7] = {0, 0, 0, 0, 0, 0, 0};
+};
+
+std::vector<Event> read_event_log(const std::string& path)
+{
+    std::ifstream in(path);
+    if (!in) { std::fprintf(stderr, "cannot open %s\n", path.c_str()); std::exit(2); }
+    std::vector<Event> ev;
+    std::string line;
+    int64_t ln = 0;
+    while (std::getline(in, line)) {
+        ++ln;
+        size_t h = line.find('#');
+        if (h != std::string::npos) line = line.substr(0, h);
+        if (line.find_first_not_of(" \t\r\n") == std::string::npos) continue;
+        std::vector<std::string> f;
+        std::stringstream ss(line);
+        std::string tok;
+        while (std::getline(ss, tok, ',')) {
+            size_t a = tok.find_first_not_of(" \t\r\n"), b = tok.find_last_not_of(" \t\r\n");
+            f.push_back(a == std::string::npos ? std::string() : tok.substr(a, b - a + 1));
+        }
+        Event e;
+        const size_t want = f[0] == "imu" ? 8 : f[0] == "tag" ? 10 : 0;
+        if (want == 0 || f.size() != want) { std::fprintf(stderr, "%s:%lld: expected `imu` + 7 numbers or `tag` + 9 numbers\n", path.c_str(), (long long)ln); std::exit(2); }
+        e.tag = f[0] == "tag";
+        e.t = std::strtod(f[1].c_str(), nullptr);
+        size_t k = 2;
+        if (e.tag) e.stamp = std::strtod(f[k++].c_str(), nullptr);
+        for (int j = 0; k < f.size(); ++k, ++j) e.v[j] = std::strtod(f[k].c_str(), nullptr);
+        if (!ev.empty() && e.t < ev.back().t) { std::fprintf(stderr, "%s:%lld: events must be ordered by arrival time\n", path.c_str(), (long long)ln); std::exit(2); }
+        ev.push_back(e);
+    }
+    return ev;
+}
+
+// The node's main loop on a recorded log (MAIN.cpp:17 single-threaded spinner): callbacks in arrival order, the
+// filter_update timer every dT_nom.  Returns the number of ticks the filter was active for.
+int run_recorded(const qle_params& p, const qle_derived& d, const std::string& log, const std::string& trace_path, int64_t B, int dtype, int device)
+{
+    const std::vector<Event> ev = read_event_log(log);
+    if (ev.empty()) { std::fprintf(stderr, "%s holds no events\n", log.c_str()); return 2; }
+    qle_batch* h = nullptr;
+    check(qle_create(&h, B, dtype, device, &p), "qle_create");
+    check(qle_enable_gating(h, 1), "qle_enable_gating");
+    check(qle_enable_aux(h, 1), "qle_enable_aux");
+    std::vector<double> u((size_t)B * 6, 0.0), z((size_t)B * 7, 0.0), stamp((size_t)B, 0.0);
+    std::vector<uint8_t> ready((size_t)B, 0), perf((size_t)B, 0), cons((size_t)B, 0);
+    std::vector<int32_t> upds((size_t)B, 0);
+    std::vector<double> pose((size_t)B * 7), cov((size_t)B * 36), vel((size_t)B * 3), bias((size_t)B * 6), accel((size_t)B * 3), obs((size_t)B * 7), delay((size_t)B, p.measurement_delay);
+    for (int64_t i = 0; i < B; ++i) z[(size_t)i * 7 + 6] = 1.0;
+    FILE* tr = nullptr;
+    if (!trace_path.empty()) {
+        tr = std::fopen(trace_path.c_str(), "w");
+        if (!tr) { std::fprintf(stderr, "cannot write %s\n", trace_path.c_str()); return 2; }
+        std::fprintf(tr, "# t,rx,ry,rz,qx,qy,qz,qw,vx,vy,vz,ax,ay,az,performed_correction,upds_since_correction,measurement_delay_curr,cov_rr_xx,cov_tt_xx\n");
+    }
+    bool state_initialized = false, measurement_ready = false;
+    int64_t n_ticks = 0, n_active = 0, n_corr = 0;
+    size_t k = 0;
+    const double t_first = ev.front().t, t_last = ev.back().t;
+    for (int64_t tick = 1;; ++tick) {
+        const double t = t_first + (double)tick * d.dT_nom;
+        if (t > t_last + 0.5 * d.dT_nom) break;
+        for (; k < ev.size() && ev[k].t <= t; ++k) {
+            const Event& e = ev[k];
+            if (!e.tag) {   // IMUSubCallback, NODE.cpp:144-151
+                for (int64_t i = 0; i < B; ++i) std::memcpy(&u[(size_t)i * 6], e.v, sizeof(double) * 6);
+            } else {        // AprilTagSubCallback, NODE.cpp:153-176
+                for (int64_t i = 0; i < B; ++i) { std::memcpy(&z[(size_t)i * 7], e.v, sizeof(double) * 7); stamp[(size_t)i] = e.stamp; }
+                measurement_ready = true;
+                if (!state_initialized) { check(qle_initialize_state(h, z.data(), 0), "qle_initialize_state"); state_initialized = true; }
+            }
+        }
+        ++n_ticks;
+        if (!state_initialized) continue;   // EKF.cpp:129-130
+        std::fill(ready.begin(), ready.end(), (uint8_t)(measurement_ready ? 1 : 0));
+        check(qle_filter_update_stamped(h, u.data(), measurement_ready ? z.data() : nullptr, measurement_ready ? ready.data() : nullptr, t, stamp.data()), "qle_filter_update_stamped");
+        check(qle_get_tick_flags(h, perf.data(), cons.data(), upds.data()), "qle_get_tick_flags");
+        if (cons[0]) measurement_ready = false;   // EKF.cpp:152 (every filter sees the same stream, so the flags agree)
+        ++n_active;
+        n_corr += perf[0];
+        if (tr) {
+            check(qle_get_report(h, pose.data(), cov.data(), vel.data(), bias.data()), "qle_get_report");
+            check(qle_get_aux(h, accel.data(), obs.data()), "qle_get_aux");
+            if (perf[0] && p.multirate_ekf) check(qle_get_measurement_delay(h, delay.data()), "qle_get_measurement_delay");
+            std::fprintf(tr, "%.9f", t);
+            for (int j = 0; j < 7; ++j) std::fprintf(tr, ",%.17g", pose[(size_t)j]);
+            for (int j = 0; j < 3; ++j) std::fprintf(tr, ",%.17g", vel[(size_t)j]);
+            for (int j = 0; j < 3; ++j) std::fprintf(tr, ",%.17g", accel[(size_t)j]);
+            std::fprintf(tr, ",%d,%d,%.17g,%.17g,%.17g\n", (int)perf[0], (int)upds[0], delay[0], cov[0], cov[21]);
+        }
+    }
+    if (tr) std::fclose(tr);
+    int64_t bad = 0;
+    check(qle_count_nonfinite(h, &bad), "qle_count_nonfinite");
+    check(qle_get_report(h, pose.data(), cov.data(), vel.data(), bias.data()), "qle_get_report");
+    std::printf("%s\n", qle_version());
+    std::printf("recorded log %s: %zu events over %.3f s, %lld timer ticks at %.1f Hz, filter active for %lld, corrections performed %lld, multirate %d\n", log.c_str(),
+                ev.size(), t_last - t_first, (long long)n_ticks, p.update_freq, (long long)n_active, (long long)n_corr, p.multirate_ekf);
+    std::printf("filter 0: rel_pose position (%.4f, %.4f, %.4f) orientation xyzw (%.4f, %.4f, %.4f, %.4f)\n", pose[0], pose[1], pose[2], pose[3], pose[4], pose[5], pose[6]);
+    std::printf("filter 0: velocity (%.4f, %.4f, %.4f)  IMU bias+static accel (%.4f, %.4f, %.4f) gyro (%.5f, %.5f, %.5f); non-finite filters: %lld\n", vel[0], vel[1], vel[2],
+                bias[0], bias[1], bias[2], bias[3], bias[4], bias[5], (long long)bad);
+    qle_destroy(h);
+    return bad == 0 ? 0 : 3;
+}
+
 }  // namespace
 
 int main(int argc, char** argv)
 {
-    std::string config;
+    std::string config, sequence, trace;
     int64_t batch = 4096, ticks = 1000;
+    bool batch_given = false;
     int dtype = QLE_F32, device = 0;
     uint64_t seed = 0xE4F00001ULL;
     double update_freq = 0, measurement_freq = 0;
@@ -99,7 +220,9 @@ int main(int argc, char** argv)
         std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return std::string(argv[++i]); };
         if (a == "--config") config = next();
-        else if (a == "--batch") batch = std::atoll(next().c_str());
+        else if (a == "--batch") { batch = std::atoll(next().c_str()); batch_given = true; }
+        else if (a == "--sequence") sequence = next();
+        else if (a == "--trace") trace = next();
         else if (a == "--ticks") ticks = std::atoll(next().c_str());
         else if (a == "--dtype") dtype = next() == "f64" ? QLE_F64 : QLE_F32;
         else if (a == "--device") device = std::atoi(next().c_str());
@@ -150,6 +273,11 @@ int main(int argc, char** argv)
     if (multirate >= 0) p.multirate_ekf = multirate;
     qle_derived d;
     check(qle_params_derive(&p, &d), "qle_params_derive");
+    if (!sequence.empty()) {
+        int32_t nd = 0;
+        check(qle_device_count(&nd), "qle_device_count");
+        return run_recorded(p, d, sequence, trace, batch_given ? batch : 1, dtype, device);
+    }
 
     // ---- shards: contiguous ranges of the global filter index, one per device
     int32_t ndev_avail = 0;

@@ -1,0 +1,148 @@
+"""Recorded IMU + tag-pose event logs through the engine (BASELINE cfg 1: one filter on a recorded sequence).
+
+The reference ships no bag, so the recording is the seeded synthetic flight `tests/golden/recorded_cfg1.csv`
+(`tests/golden/make_recorded.py`).  The node's loop (NODE.cpp:144-182) is replayed three ways on the same log --
+the oracle's one-filter object, `quadrotor_landing_amd.replay.replay` and `ekf_driver --sequence` -- and the
+published values are compared tick by tick."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import quadrotor_landing_amd as qla
+from quadrotor_landing_amd import replay as rp
+from util import GOLDEN, oracle_replay, orc_params_from_qle
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOG = os.path.join(GOLDEN, "recorded_cfg1.csv")
+CFG = os.path.join(ROOT, "quadrotor_landing_amd", "config", "ekf_sim_rotors.yaml")
+EXE = os.path.join(ROOT, "quadrotor_landing_amd", "ekf_driver")
+
+VARIANTS = {  # cfg 1 rates (ROTORS.yaml:3-4): 100 Hz filter, 15 Hz tag
+    "as_shipped": dict(),                                          # multirate + dynamic delay + corner gate
+    "fixed_delay": dict(dynamic_meas_delay=0),
+    "single_rate": dict(multirate_ekf=0),
+    "conventional_nobias": dict(multirate_ekf=0, direct_orien_method=0, est_bias=0),
+}
+
+
+def params(variant):
+    qp = qla.load_yaml(CFG)
+    qla.set_fields(qp, update_freq=100.0, measurement_freq=15.0, **VARIANTS[variant])
+    return qp
+
+
+def test_event_log_round_trip(tmp_path):
+    ev = rp.read_event_log(LOG)
+    assert sum(e[0] == "imu" for e in ev) == 1000 and sum(e[0] == "tag" for e in ev) >= 145
+    out = tmp_path / "copy.csv"
+    rp.write_event_log(str(out), ev)
+    ev2 = rp.read_event_log(str(out))
+    assert len(ev) == len(ev2)
+    for a, b in zip(ev, ev2):
+        assert a[0] == b[0] and a[1] == b[1] and np.array_equal(a[-1], b[-1])
+    bad = tmp_path / "bad.csv"
+    bad.write_text("imu,0.1,1,2,3\n")
+    with pytest.raises(ValueError):
+        rp.read_event_log(str(bad))
+    bad.write_text("imu,0.2,1,2,3,4,5,6\nimu,0.1,1,2,3,4,5,6\n")
+    with pytest.raises(ValueError):
+        rp.read_event_log(str(bad))
+
+
+@pytest.mark.parametrize("variant", list(VARIANTS))
+def test_oracle_filter_tracks_the_recorded_flight(variant):
+    """The checker itself on the log: it corrects at the tag rate and stays on the tag-derived pose."""
+    p = orc_params_from_qle(params(variant))
+    ev = rp.read_event_log(LOG)
+    tr = oracle_replay(p, ev)
+    assert np.isfinite(tr).all() and tr.shape[0] > 990
+    assert 130 <= tr[:, 20].sum() <= 150                       # 15 Hz tag, limit = every 7th tick of 100 Hz
+    last_tag = [e for e in ev if e[0] == "tag"][-1]
+    r_obs, _ = oracle.seed_pose(p, last_tag[3][:3], last_tag[3][3:])
+    assert np.linalg.norm(tr[-1, 1:4] - r_obs) < 0.5
+    if p.multirate_ekf and p.dynamic_meas_delay:
+        assert 0.03 < tr[:, 22].max() < 0.2                    # measured camera latency + wait for the rate limit
+
+
+def test_driver_sequence_mode_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc")], check=True, capture_output=True)
+    r = subprocess.run([EXE, "--config", CFG, "--sequence", LOG], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "no CPU fallback" in r.stderr
+
+
+def _engine_trace(variant, dtype, batch):
+    ekf = qla.BatchedRelativePoseEKF(batch, dtype, params=params(variant))
+    ekf.enable_aux(True)
+    rows = []
+
+    def on_tick(t, e, perf, upds):
+        x, P = e.get_state()
+        acc, _ = e.get_aux()
+        d = e.measurement_delay()
+        n = P.shape[1]
+        for i in range(1, batch):                              # every filter sees the same stream
+            assert np.array_equal(x[i], x[0])
+        rows.append(np.concatenate([[t], x[0], acc[0], [perf[0], upds[0], d[0], P[0, 0, 0], P[0, 6, 6] if n > 6 else 0.0]]))
+
+    n_ticks, n_active, n_corr = rp.replay(ekf, rp.read_event_log(LOG), on_tick)
+    ekf.close()
+    assert n_active == len(rows)
+    return np.array(rows), n_corr
+
+
+def _compare(tr, ref, tol, multirate):
+    assert tr.shape == ref.shape
+    assert np.array_equal(tr[:, 0], ref[:, 0])
+    assert np.array_equal(tr[:, 20], ref[:, 20]) and np.array_equal(tr[:, 21], ref[:, 21])   # same decisions on every tick
+    q, qr = tr[:, 7:11], ref[:, 7:11]
+    sgn = np.sign(np.sum(q * qr, axis=1, keepdims=True))
+    np.testing.assert_allclose(q * sgn, qr, rtol=0, atol=tol)
+    for cols in (slice(1, 7), slice(11, 20)):
+        np.testing.assert_allclose(tr[:, cols], ref[:, cols], rtol=tol, atol=tol)
+    np.testing.assert_allclose(tr[:, 23:25], ref[:, 23:25], rtol=max(tol * 10, 1e-9), atol=0)
+    if multirate:                                              # measurement_delay_curr is only set by the multirate branch (EKF.cpp:199)
+        perf = ref[:, 20] > 0
+        np.testing.assert_allclose(tr[perf, 22], ref[perf, 22], rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", list(VARIANTS))
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 5e-3)])
+def test_python_replay_matches_oracle_filter(variant, dtype, tol):
+    ref = oracle_replay(orc_params_from_qle(params(variant)), rp.read_event_log(LOG))
+    tr, n_corr = _engine_trace(variant, dtype, batch=3)
+    assert n_corr == int(ref[:, 20].sum())
+    _compare(tr, ref, tol, VARIANTS[variant].get("multirate_ekf", 1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["as_shipped", "single_rate"])
+def test_driver_sequence_trace_matches_oracle_filter(tmp_path, variant):
+    """ekf_driver --sequence LOG --trace OUT: the ROS-free node on a recorded log, fp64, against the oracle."""
+    subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc")], check=True, capture_output=True)
+    out = tmp_path / "trace.csv"
+    cmd = [EXE, "--config", CFG, "--update-freq", "100", "--measurement-freq", "15", "--dtype", "f64", "--sequence", LOG, "--trace", str(out)]
+    if variant == "single_rate":
+        cmd += ["--multirate", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    print(r.stdout, r.stderr)
+    assert r.returncode == 0, r.stdout + r.stderr
+    tr = np.loadtxt(str(out), delimiter=",", comments="#")
+    ref = oracle_replay(orc_params_from_qle(params(variant)), rp.read_event_log(LOG))
+    # driver columns: t, pose7 (r, q), v3, accel3, performed, upds, delay, P_rr_xx, P_tt_xx
+    assert tr.shape[0] == ref.shape[0]
+    assert np.array_equal(tr[:, 14], ref[:, 20]) and np.array_equal(tr[:, 15], ref[:, 21])
+    np.testing.assert_allclose(tr[:, 0], ref[:, 0], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(tr[:, 1:4], ref[:, 1:4], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(tr[:, 8:11], ref[:, 4:7], rtol=1e-9, atol=1e-9)
+    sgn = np.sign(np.sum(tr[:, 4:8] * ref[:, 7:11], axis=1, keepdims=True))
+    np.testing.assert_allclose(tr[:, 4:8] * sgn, ref[:, 7:11], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(tr[:, 11:14], ref[:, 17:20], rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(tr[:, 17:19], ref[:, 23:25], rtol=1e-8, atol=0)
+    assert "corrections performed %d" % int(ref[:, 20].sum()) in r.stdout

@@ -117,3 +117,38 @@ def assert_state_close(x, P, xr, Pr, rtol, atol, qtol=None):
     scale = np.sqrt(np.einsum("bii->bi", Pr)[:, :, None] * np.einsum("bii->bi", Pr)[:, None, :])
     err = np.abs(P - Pr) / (scale + 1e-300)
     assert err.max() <= rtol * 50 + 0 * atol, err.max()
+
+
+def orc_params_from_qle(qp):
+    """oracle parameter block from an engine parameter block (field-for-field; used with load_yaml)."""
+    kw = {}
+    orc_fields = {n for n, _ in oracle.OrcParams._fields_}
+    derived = {"dT_nom", "upd_per_meas", "num_states", "measurement_step_delay", "Q", "R", "cov_init", "C_vc"}
+    for name, _ in type(qp)._fields_:
+        if name in orc_fields and name not in derived:
+            v = getattr(qp, name)
+            kw[name] = list(v) if hasattr(v, "__len__") else v
+    return oracle.make_params(**kw)
+
+
+def oracle_replay(p, events):
+    """The reference node's loop on a recorded event log with the oracle's one-filter object
+    (same schedule as quadrotor_landing_amd.replay.replay / ekf_driver --sequence).
+    -> rows [t, x16, accel3, performed, upds, delay, P00, Ptt00] per active tick."""
+    from quadrotor_landing_amd.replay import tick_times
+    f = oracle.Filter(p)
+    rows, k = [], 0
+    for t in tick_times(events, 1.0 / p.update_freq):
+        while k < len(events) and events[k][1] <= t:
+            e = events[k]; k += 1
+            if e[0] == "imu":
+                f.set_imu(e[2][:3], e[2][3:])
+            else:
+                f.set_apriltag(e[3][:3], e[3][3:], e[2])
+        if not f.f.state_initialized:
+            continue
+        f.filter_update(t)
+        P = f.P()
+        rows.append(np.concatenate([[t], f.x(), list(f.f.accel_rel), [f.f.performed_correction, f.f.upds_since_correction,
+                                                                      f.f.measurement_delay_curr, P[0, 0], P[6, 6]]]))
+    return np.array(rows)
