@@ -91,6 +91,25 @@ __host__ __device__ inline int64_t word_off(int w, int64_t i, int WT)
 // Tile index of filter i, as a wave-uniform (SGPR) value: the 64 lanes of a wave always belong to one
 // tile (blocks are multiples of 64 threads), so the tile base can live in scalar registers and the
 // loads/stores use the scalar-base + per-lane-offset addressing form instead of 64-bit VALU adds.
+// Block index -> position in the batch (XCD-aware).  Workgroups are dispatched round-robin over the 8 XCDs
+// (block b runs on XCD b % 8), so with the identity map every XCD touches every 8th 4-tile group of the state.
+// Giving each XCD one contiguous eighth of the batch instead measured +3 % on k_predict at 65 536 filters,
+// +3 % at 262 144, +1-2 % at 1 M, -1 % at 131 072 (profiles/r01_tuning.md section 4).  The map is a bijection
+// on [0, gridDim.x): the first 8*floor(n/8) blocks are transposed, the ragged rest keeps its index.
+// -DQLE_XCD_CHUNK=0 restores the identity map.
+#ifndef QLE_XCD_CHUNK
+#define QLE_XCD_CHUNK 1
+#endif
+__device__ __forceinline__ int64_t batch_block()
+{
+#if QLE_XCD_CHUNK
+    const unsigned b = blockIdx.x, n8 = gridDim.x & ~7u;
+    return b < n8 ? (int64_t)((b & 7u) * (n8 >> 3) + (b >> 3)) : (int64_t)b;
+#else
+    return (int64_t)blockIdx.x;
+#endif
+}
+
 __device__ __forceinline__ int64_t wave_tile(int64_t i) { return (int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 6)); }
 
 // Load words [W0, W0+W) of filter i's WT-word record.  W0 and W are whole quads,
@@ -243,7 +262,7 @@ template <typename T, bool PFP, int NT, bool MR>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
@@ -290,7 +309,7 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
                                                  T* __restrict__ aux_accel, T* __restrict__ aux_obs,
                                                  int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], Po[kPW], P[kPW], u[kUW], zr[kZW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
@@ -374,7 +393,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
                                                     int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, double* __restrict__ delay_out,
                                                     int64_t B)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3] = {T(0), T(0), T(0)};
     T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
@@ -459,7 +478,7 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
                                                          const int32_t* __restrict__ slot, int64_t pitch_u, int64_t pitch_z, int64_t T_seq,
                                                          int64_t t0, int64_t n, const T* __restrict__ pfp, int64_t B)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], un[kUW], accel[3];
     load_rec<T, kSW, 0, kXW>(st, i, x);
@@ -505,7 +524,7 @@ template <typename T, bool DIRECT, bool PFP>
 __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ st, const T* __restrict__ zs,
                                                    const T* __restrict__ pfp, T* __restrict__ aux_obs, int64_t B)
 {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T zr[kZW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
