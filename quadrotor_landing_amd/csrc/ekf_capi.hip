@@ -145,7 +145,8 @@ struct qle_batch {
     int32_t dtype = QLE_F32;
     int32_t device = 0;
     int32_t block = 256;
-    int32_t nt = 0;        // cache policy of the hot kernels' streaming accesses (0 default, 2 non-temporal)
+    bool nt_refresh = false;  // nt == 1 and the state is <= 40 MiB: non-temporal stores with the periodic cached-store tick
+    int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal
     int64_t rows_max = 0;  // batches up to this size may use the rows-across-lanes kernel (ekf_rows.hpp)
     bool rows_forced = false;  // QLE_ROWS_MAX set: use it for every eligible tick (tests, experiments)
     size_t wsz = 4;
@@ -331,13 +332,19 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     h->dtype = dtype;
     h->device = device;
     h->wsz = dtype == QLE_F32 ? 4 : 8;
-    {   // Cache policy, measured on MI355X (profiles/r01_tuning.md): non-temporal loads+stores are faster
-        // when the state is about the size of the aggregate L2 or smaller (shorter kernel boundaries: less
-        // dirty L2 to flush) and when it is far larger than the 256 MiB Infinity Cache (pure streaming);
-        // in between, the default policy keeps the state resident in the Infinity Cache.
+    {   // Cache policy of the state accesses, from SUSTAINED rates on MI355X (profiles/r01_tuning.md section 5;
+        // the input records are always read non-temporally):
+        //   state <= 40 MiB (about the aggregate L2): non-temporal loads and stores with a cached-store tick every
+        //     128 ticks that keeps the state allocated in the Infinity Cache (effective_nt below);
+        //   up to 48 MiB: non-temporal loads, cached stores;
+        //   up to 500 MiB: cached loads and stores (Infinity-Cache resident from tick to tick; still ahead at
+        //     432 MiB, level at 360 MiB);
+        //   beyond: non-temporal loads and stores (pure streaming; +9 % at 576 MiB).
+        // QLE_NT=0|1|2 overrides (0 cached, 1 the L2-sized scheme, 2 non-temporal loads+stores on every tick).
         const double state_mib = (double)kSW * (double)h->Bp * (double)h->wsz / (1024.0 * 1024.0);
-        h->nt = (state_mib <= 38.0 || state_mib >= 300.0) ? 2 : 0;
-        if (const char* s = std::getenv("QLE_NT")) h->nt = std::atoi(s) >= 1 ? 2 : 0;
+        h->nt = state_mib <= 48.0 ? 1 : (state_mib >= 500.0 ? 2 : 0);
+        h->nt_refresh = state_mib <= 40.0;   // at 45 MiB the refresh scheme loses (18.2 vs 16.3 us), plain policy 1 wins
+        if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(2, std::max(0, std::atoi(s)));
     }
     // Rows-across-lanes kernel (16 lanes per filter).  Measured (profiles/r01_tuning.md section 3): its per-wave
     // instruction stream is as long as the one-lane-per-filter kernels', so it only pays where those spill:
@@ -583,6 +590,20 @@ static int launch_rows(qle_batch* h, const void* u, const void* z)
     return QLE_OK;
 }
 
+// Kernel cache policy of this tick.  For an L2-sized state (h->nt == 1) the fastest sustained scheme measured
+// (profiles/r01_tuning.md section 5) is: non-temporal loads AND stores -- the stores update the lines the state
+// already has in the Infinity Cache and leave no dirty L2 to flush at the kernel boundary -- plus one tick with
+// cached stores every kRefreshTicks, which re-allocates the state in the Infinity Cache.  Without the refresh the
+// state drifts out of the cache within ~3 000 ticks and every tick streams from HBM (9.3 -> 10.9 us per predict
+// at 65 536 filters); cached stores on every tick cost 9.9 us.  QLE_REFRESH=R overrides (0: cached stores always).
+constexpr int kRefreshTicks = 128;
+static inline int effective_nt(const qle_batch* h)
+{
+    static const int refresh = [] { const char* s = std::getenv("QLE_REFRESH"); return s ? std::atoi(s) : kRefreshTicks; }();
+    if (h->nt == 1 && h->nt_refresh && refresh > 0) return (h->tick % refresh) == 0 ? 1 : 2;
+    return h->nt;
+}
+
 // prediction_step from `src` into `dst`; keep_u: the record also stores the IMU sample (multirate history).
 template <typename T>
 static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u)
@@ -592,13 +613,12 @@ static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void*
     T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
 #define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B)
-    if (keep_u) {
-        if (h->nt) { if (h->pfp_on) QLE_PRED(true, 2, true); else QLE_PRED(false, 2, true); }
-        else { if (h->pfp_on) QLE_PRED(true, 0, true); else QLE_PRED(false, 0, true); }
-    } else {
-        if (h->nt) { if (h->pfp_on) QLE_PRED(true, 2, false); else QLE_PRED(false, 2, false); }
-        else { if (h->pfp_on) QLE_PRED(true, 0, false); else QLE_PRED(false, 0, false); }
-    }
+#define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
+    const int nt = effective_nt(h);
+#define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)
+    if (keep_u) QLE_PRED_M(true); else QLE_PRED_M(false);
+#undef QLE_PRED_M
+#undef QLE_PRED_N
 #undef QLE_PRED
     HIP_TRY(hipGetLastError());
     return QLE_OK;
@@ -642,8 +662,10 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
 #define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B)
-    if (h->nt) { if (h->pfp_on) QLE_STEP_LAUNCH(true, 2); else QLE_STEP_LAUNCH(false, 2); }
-    else { if (h->pfp_on) QLE_STEP_LAUNCH(true, 0); else QLE_STEP_LAUNCH(false, 0); }
+#define QLE_STEP_N(N) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N); else QLE_STEP_LAUNCH(false, N); } while (0)
+    const int nt = effective_nt(h);
+    if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);
+#undef QLE_STEP_N
 #undef QLE_STEP_LAUNCH
     HIP_TRY(hipGetLastError());
     return QLE_OK;

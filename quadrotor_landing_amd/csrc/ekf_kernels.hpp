@@ -43,10 +43,11 @@ constexpr int kUW = 6;      // IMU words
 constexpr int kZW = 8;      // tag pose 7 words + mask word
 constexpr int kFW = 24;     // per-filter parameter words
 
-// 16-byte quads as native vectors (global_load/store_dwordx4).  NT selects the cache policy of the
-// streaming state/input accesses of the hot kernels: 0 = default, 2 = non-temporal loads and stores.
-// Every state byte is read once and written once per launch; which policy is faster depends on
-// whether the state fits the 256 MiB Infinity Cache (chosen per handle, see ekf_capi.hip).
+// 16-byte quads as native vectors (global_load/store_dwordx4).  NT selects the cache policy of the hot kernels'
+// state accesses: 0 = cached loads and stores (the state lives in the 256 MiB Infinity Cache from tick to tick),
+// 1 = non-temporal loads, cached stores, 2 = non-temporal loads and stores.  Every state byte is read once and
+// written once per launch; which policy sustains the highest rate depends on the state size (chosen per handle,
+// see ekf_capi.hip).  The input records are always read non-temporally.
 typedef float qle_f4 __attribute__((ext_vector_type(4)));
 typedef double qle_d2 __attribute__((ext_vector_type(2)));
 typedef float qle_f2 __attribute__((ext_vector_type(2)));
@@ -54,10 +55,16 @@ template <typename T> struct Quad;
 template <> struct Quad<float> { using type = qle_f4; static constexpr int VW = 4; };
 template <> struct Quad<double> { using type = qle_d2; static constexpr int VW = 2; };
 
+// Which accesses of a hot kernel are non-temporal under policy NT (profiles/r01_tuning.md section 5, sustained rates):
+//   IMU / tag records (read once, never again): always non-temporal, so the input stream does not displace the state
+//   in the Infinity Cache; state and per-filter parameter records: loads non-temporal for NT >= 1, stores for NT >= 2.
+template <int NT, int WT> struct NtLd { static constexpr int value = (WT == kUW || WT == kZW || NT >= 1) ? 2 : 0; };
+template <int NT> struct NtSt { static constexpr int value = NT >= 2 ? 2 : 0; };
+
 template <int NT, typename Q>
 __device__ __forceinline__ Q ld_quad(const Q* ptr)
 {
-    if (NT >= 2) return __builtin_nontemporal_load(ptr);
+    if (NT >= 1) return __builtin_nontemporal_load(ptr);
     return *ptr;
 }
 template <int NT, typename Q>
@@ -129,11 +136,11 @@ __device__ __forceinline__ void load_rec(const T* __restrict__ base, int64_t i, 
     const T* tb = base + tile * (int64_t)(WT * kTile);
 #pragma unroll
     for (int k = 0; k < NF; ++k) {
-        Q v = ld_quad<NT>(reinterpret_cast<const Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW));
+        Q v = ld_quad<NtLd<NT, WT>::value>(reinterpret_cast<const Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW));
         unpack_quad(v, &r[k * VW]);
     }
     if (REM == 2) {
-        qle_f2 v = ld_quad<NT>(reinterpret_cast<const qle_f2*>(tb + NFT * VW * kTile + lane * 2));
+        qle_f2 v = ld_quad<NtLd<NT, WT>::value>(reinterpret_cast<const qle_f2*>(tb + NFT * VW * kTile + lane * 2));
         r[NF * VW] = v.x;
         r[NF * VW + 1] = v.y;
     }
@@ -150,7 +157,7 @@ __device__ __forceinline__ void store_rec(T* __restrict__ base, int64_t i, const
     const int lane = (int)(i & 63);
     T* tb = base + tile * (int64_t)(WT * kTile);
 #pragma unroll
-    for (int k = 0; k < NF; ++k) st_quad<NT>(reinterpret_cast<Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW), pack_quad(&r[k * VW]));
+    for (int k = 0; k < NF; ++k) st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW), pack_quad(&r[k * VW]));
 }
 
 template <typename T, bool PFP>
@@ -187,7 +194,7 @@ __device__ __forceinline__ void load_P_quads_desc(const T* __restrict__ st, int6
     const T* tb = st + tile * (int64_t)(kSW * kTile);
 #pragma unroll
     for (int k = Q1 - 1; k >= Q0; --k) {
-        Q v = ld_quad<NT>(reinterpret_cast<const Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW));
+        Q v = ld_quad<NtLd<NT, kSW>::value>(reinterpret_cast<const Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW));
         unpack_quad(v, &P[k * VW]);
     }
 }
@@ -200,7 +207,7 @@ __device__ __forceinline__ void store_P_quads_desc(T* __restrict__ st, int64_t i
     const int lane = (int)(i & 63);
     T* tb = st + tile * (int64_t)(kSW * kTile);
 #pragma unroll
-    for (int k = Q1 - 1; k >= Q0; --k) st_quad<NT>(reinterpret_cast<Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW), pack_quad(&P[k * VW]));
+    for (int k = Q1 - 1; k >= Q0; --k) st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW), pack_quad(&P[k * VW]));
 }
 
 // --------------------------------------------------------- measurement gate
