@@ -84,6 +84,11 @@ def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
 
 
 def main():
+    # stdout carries exactly ONE JSON line (rank 0).  Libraries print there too (gloo announces its peers on
+    # stdout), so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
@@ -258,7 +263,7 @@ def main():
     if x0 is not None:
         out["cpu_baseline"] = cpu_baseline(seq, x0, P0, min(B, 65536), min(140, T))
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     ekf.close()
     if dist is not None:
         dist.destroy_process_group()

@@ -47,3 +47,21 @@ def test_bench_json_contract(extra):
         assert d["dtype"] == "f32"
     if extra == ["--workload", "cfg2"]:
         assert d["dtype"] == "f64"
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_print_one_json_line():
+    """The driver's N > 1 launch line, rehearsed with both ranks on the one GPU of the box: stdout of the whole job is
+    exactly one JSON line (gloo's own chatter must not land there), value = units of all ranks / max-over-ranks time."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "42", "--warmup", "14",
+           "--batch-per-gpu", "4096", "--predict-only-steps", "60"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["scaling"] == "weak"
+    assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert "cpu_baseline" not in d          # rank 0 at N = 1 only
