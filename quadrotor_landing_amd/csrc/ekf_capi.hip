@@ -355,6 +355,9 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         const long long v = std::atoll(s);
         if (v >= 16) h->rebase_at = v;
     }
+    // Workgroup size of the hot kernels: 256 threads (4 tiles) up to 131 072 filters; one wave per workgroup beyond
+    // (finer dispatch: +2-3 % at 262 144 and 524 288 filters, +1.5 % at 1-2 M, level below; profiles/r01_tuning.md section 4).
+    h->block = batch >= 262144 ? 64 : kBlock;
     if (const char* s = std::getenv("QLE_BLOCK")) {
         int b = std::atoi(s);
         if (b == 64 || b == 128 || b == 256) h->block = b;
