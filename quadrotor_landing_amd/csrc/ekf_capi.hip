@@ -145,7 +145,7 @@ struct qle_batch {
     int32_t dtype = QLE_F32;
     int32_t device = 0;
     int32_t block = 256;
-    bool nt_refresh = false;  // nt == 1 and the state is <= 40 MiB: non-temporal stores with the periodic cached-store tick
+    int32_t nt_refresh = 0;   // > 0: nt == 1 and the state is <= 40 MiB: non-temporal stores, cached-store tick every nt_refresh ticks
     int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal
     int64_t rows_max = 0;  // batches up to this size may use the rows-across-lanes kernel (ekf_rows.hpp)
     bool rows_forced = false;  // QLE_ROWS_MAX set: use it for every eligible tick (tests, experiments)
@@ -343,7 +343,8 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         // QLE_NT=0|1|2 overrides (0 cached, 1 the L2-sized scheme, 2 non-temporal loads+stores on every tick).
         const double state_mib = (double)kSW * (double)h->Bp * (double)h->wsz / (1024.0 * 1024.0);
         h->nt = state_mib <= 48.0 ? 1 : (state_mib >= 500.0 ? 2 : 0);
-        h->nt_refresh = state_mib <= 40.0;   // at 45 MiB the refresh scheme loses (18.2 vs 16.3 us), plain policy 1 wins
+        h->nt_refresh = state_mib <= 40.0 ? 128 : 0;   // at 45 MiB the refresh scheme loses (18.2 vs 16.3 us), plain policy 1 wins
+        if (const char* s = std::getenv("QLE_REFRESH")) h->nt_refresh = std::max(0, std::atoi(s));
         if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(2, std::max(0, std::atoi(s)));
     }
     // Rows-across-lanes kernel (16 lanes per filter).  Measured (profiles/r01_tuning.md section 3): its per-wave
@@ -596,14 +597,12 @@ static int launch_rows(qle_batch* h, const void* u, const void* z)
 // Kernel cache policy of this tick.  For an L2-sized state (h->nt == 1) the fastest sustained scheme measured
 // (profiles/r01_tuning.md section 5) is: non-temporal loads AND stores -- the stores update the lines the state
 // already has in the Infinity Cache and leave no dirty L2 to flush at the kernel boundary -- plus one tick with
-// cached stores every kRefreshTicks, which re-allocates the state in the Infinity Cache.  Without the refresh the
+// cached stores every nt_refresh (128) ticks, which re-allocates the state in the Infinity Cache.  Without the refresh the
 // state drifts out of the cache within ~3 000 ticks and every tick streams from HBM (9.3 -> 10.9 us per predict
 // at 65 536 filters); cached stores on every tick cost 9.9 us.  QLE_REFRESH=R overrides (0: cached stores always).
-constexpr int kRefreshTicks = 128;
 static inline int effective_nt(const qle_batch* h)
 {
-    static const int refresh = [] { const char* s = std::getenv("QLE_REFRESH"); return s ? std::atoi(s) : kRefreshTicks; }();
-    if (h->nt == 1 && h->nt_refresh && refresh > 0) return (h->tick % refresh) == 0 ? 1 : 2;
+    if (h->nt == 1 && h->nt_refresh > 0) return (h->tick % h->nt_refresh) == 0 ? 1 : 2;
     return h->nt;
 }
 

@@ -394,6 +394,41 @@ def test_cfg3_full_size_properties_fp32():
     ekf.close()
 
 
+def test_launch_rules_do_not_change_results_large_ragged_batch(monkeypatch):
+    """The launch rules chosen from the batch size -- XCD-chunked block map, workgroup size (64 threads from 262 144
+    filters on), cache policy incl. the periodic cached-store tick of small states -- are invisible in the results:
+    a 262 244-filter batch (ragged: not a multiple of 64, grid not a multiple of 8) and a 65 536-filter shard of the
+    same global population agree BIT FOR BIT over 280 ticks, and so does the shard with every rule overridden."""
+    kw = golden_kwargs("rotors400")
+    pq = qla.make_params(**kw)
+    T = 280
+    thm = np.zeros(T, np.uint8); thm[13::14] = 1
+
+    def run(B, offset):
+        e = qla.BatchedRelativePoseEKF(B, "f32", params=pq)
+        s = e.make_inputs(T, thm)
+        e.synth_generate(s, seed=0xE4F00004, filter_offset=offset)
+        e.run(s, 0, T)
+        assert e.count_nonfinite() == 0
+        x, P = e.get_state()
+        e.close()
+        return x, P
+
+    Bbig, off, Bs = 262144 + 100, 131072, 65536
+    xb, Pb = run(Bbig, 0)                                  # cached policy, 64-thread workgroups, ragged grid
+    xs, Ps = run(Bs, off)                                  # non-temporal + refresh tick, 256-thread workgroups
+    np.testing.assert_array_equal(xs, xb[off:off + Bs])
+    np.testing.assert_array_equal(Ps, Pb[off:off + Bs])
+    np.testing.assert_array_equal(run(100, 262144)[0], xb[262144:])   # the ragged tail
+    for env in (dict(QLE_NT="0", QLE_BLOCK="64"), dict(QLE_NT="2", QLE_BLOCK="128"), dict(QLE_NT="1", QLE_REFRESH="3")):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        xo, Po = run(Bs, off)
+        np.testing.assert_array_equal(xo, xs); np.testing.assert_array_equal(Po, Ps)
+        for k in env:
+            monkeypatch.delenv(k)
+
+
 # ------------------------------------------- filter_update decision logic
 HW_TAGS = dict(
     n_tags=13, tag_in_view_margin=0.0,
