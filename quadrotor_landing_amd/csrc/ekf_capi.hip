@@ -145,8 +145,9 @@ struct qle_batch {
     int32_t dtype = QLE_F32;
     int32_t device = 0;
     int32_t block = 256;
+    int32_t split = 0;        // nt == 3: which workgroups keep their tiles cached (cached_workgroup() in ekf_kernels.hpp)
     int32_t nt_refresh = 0;   // > 0: nt == 1 and the state is <= 40 MiB: non-temporal stores, cached-store tick every nt_refresh ticks
-    int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal
+    int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal, 3 split
     int64_t rows_max = 0;  // batches up to this size may use the rows-across-lanes kernel (ekf_rows.hpp)
     bool rows_forced = false;  // QLE_ROWS_MAX set: use it for every eligible tick (tests, experiments)
     size_t wsz = 4;
@@ -337,15 +338,23 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         //   state <= 40 MiB (about the aggregate L2): non-temporal loads and stores with a cached-store tick every
         //     128 ticks that keeps the state allocated in the Infinity Cache (effective_nt below);
         //   up to 48 MiB: non-temporal loads, cached stores;
-        //   up to 500 MiB: cached loads and stores (Infinity-Cache resident from tick to tick; still ahead at
-        //     432 MiB, level at 360 MiB);
-        //   beyond: non-temporal loads and stores (pure streaming; +9 % at 576 MiB).
-        // QLE_NT=0|1|2 overrides (0 cached, 1 the L2-sized scheme, 2 non-temporal loads+stores on every tick).
+        //   up to 300 MiB: cached loads and stores (Infinity-Cache resident from tick to tick);
+        //   beyond: "split" -- a fixed ~216 MiB of the state stays cached, the rest streams non-temporally, so the
+        //     Infinity Cache and HBM serve the tick side by side (+25 % at 432 and 576 MiB, +17 % at 1.1 GB, +8 % at
+        //     2.3 GB over streaming everything).
+        // QLE_NT=0|1|2|3 overrides (0 cached, 1 the L2-sized scheme, 2 non-temporal loads+stores, 3 split with
+        // QLE_SPLIT=-k: k of every 64 workgroup groups cached).
         const double state_mib = (double)kSW * (double)h->Bp * (double)h->wsz / (1024.0 * 1024.0);
-        h->nt = state_mib <= 48.0 ? 1 : (state_mib >= 500.0 ? 2 : 0);
+        h->nt = state_mib <= 48.0 ? 1 : (state_mib <= 300.0 ? 0 : 3);
         h->nt_refresh = state_mib <= 40.0 ? 128 : 0;   // at 45 MiB the refresh scheme loses (18.2 vs 16.3 us), plain policy 1 wins
         if (const char* s = std::getenv("QLE_REFRESH")) h->nt_refresh = std::max(0, std::atoi(s));
-        if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(2, std::max(0, std::atoi(s)));
+        // larger than the cache: keep about 216 MiB of the state cached (k of every 64 workgroup groups, interleaved
+        // over the batch and spread evenly over the XCDs) and stream the rest
+        const int k64 = (int)std::lround(64.0 * 216.0 / std::max(state_mib, 1.0));
+        h->split = -std::min(63, std::max(1, k64));
+        if (state_mib > 64.0 * 240.0) h->nt = 2;       // even 1/64 of it would not fit: stream everything
+        if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(3, std::max(0, std::atoi(s)));
+        if (const char* s = std::getenv("QLE_SPLIT")) h->split = std::atoi(s);
     }
     // Rows-across-lanes kernel (16 lanes per filter).  Measured (profiles/r01_tuning.md section 3): its per-wave
     // instruction stream is as long as the one-lane-per-filter kernels', so it only pays where those spill:
@@ -603,6 +612,7 @@ static int launch_rows(qle_batch* h, const void* u, const void* z)
 static inline int effective_nt(const qle_batch* h)
 {
     if (h->nt == 1 && h->nt_refresh > 0) return (h->tick % h->nt_refresh) == 0 ? 1 : 2;
+    if (h->nt == 3 && h->mr) return 2;   // the split policy is for the in-place single-rate state
     return h->nt;
 }
 
@@ -614,11 +624,13 @@ static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void*
     const dim3 g = grid_for(h, h->block), b(h->block);
     T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B)
+#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B, h->split)
 #define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
     const int nt = effective_nt(h);
 #define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)
-    if (keep_u) QLE_PRED_M(true); else QLE_PRED_M(false);
+    if (keep_u) QLE_PRED_M(true);
+    else if (nt == 3) QLE_PRED_N(3, false);
+    else QLE_PRED_M(false);
 #undef QLE_PRED_M
 #undef QLE_PRED_N
 #undef QLE_PRED
@@ -663,10 +675,10 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     const dim3 g = grid_for(h, h->block), b(h->block);
     T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B)
+#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split)
 #define QLE_STEP_N(N) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N); else QLE_STEP_LAUNCH(false, N); } while (0)
     const int nt = effective_nt(h);
-    if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);
+    if (nt == 3) QLE_STEP_N(3); else if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);
 #undef QLE_STEP_N
 #undef QLE_STEP_LAUNCH
     HIP_TRY(hipGetLastError());

@@ -266,11 +266,9 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 // filter (in place: every load of a lane is issued before its first store), two ring slots for the
 // multirate filter (MR: the record also keeps the IMU sample, EKF.cpp:254-256).
 template <typename T, bool PFP, int NT, bool MR>
-__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
-                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B)
+__device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src, T* dst, const T* __restrict__ us,
+                                             const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t i)
 {
-    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
-    if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
     load_rec<T, kSW, 0, kXW, NT>(src, i, x);
@@ -307,17 +305,38 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
     }
 }
 
+// NT == 3 ("split", states larger than the Infinity Cache): the workgroups selected by `split` keep their tiles
+// cached (policy 0), all others stream (policy 2), so a fixed part of the state that fits the cache stays resident
+// from tick to tick.  split >= 0: the first `split` dispatched workgroups (spread over all XCDs by batch_block());
+// split < 0: interleaved, workgroups with ((blockIdx.x >> 3) & 63) < -split, i.e. -split/64 of every XCD's share.
+__device__ __forceinline__ bool cached_workgroup(int32_t split)
+{
+    return split >= 0 ? blockIdx.x < (unsigned)split : ((blockIdx.x >> 3) & 63u) < (unsigned)(-split);
+}
+
+template <typename T, bool PFP, int NT, bool MR>
+__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
+                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B, int32_t split)
+{
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    if (NT == 3) {
+        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR>(p, src, dst, us, pfp, aux_accel, i);
+        else predict_tick<T, PFP, 2, MR>(p, src, dst, us, pfp, aux_accel, i);
+    } else {
+        predict_tick<T, PFP, NT, MR>(p, src, dst, us, pfp, aux_accel, i);
+    }
+}
+
 // Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290):
 // predict, then correct where the record's mask word is non-zero.
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
 template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
-__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
-                                                 const T* __restrict__ zs, const T* __restrict__ pfp,
-                                                 T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B)
+__device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParams& gp, T* st, const T* __restrict__ us,
+                                          const T* __restrict__ zs, const T* __restrict__ pfp,
+                                          T* __restrict__ aux_accel, T* __restrict__ aux_obs,
+                                          int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t i)
 {
-    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
-    if (i >= B) return;
     T x[kXW], Po[kPW], P[kPW], u[kUW], zr[kZW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
     load_rec<T, kZW, 0, kZW, NT>(zs, i, zr);
@@ -352,6 +371,22 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
 #pragma unroll
             for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
         }
+    }
+}
+
+template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
+__global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
+                                                 const T* __restrict__ zs, const T* __restrict__ pfp,
+                                                 T* __restrict__ aux_accel, T* __restrict__ aux_obs,
+                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
+{
+    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    if (NT == 3) {   // see k_predict
+        if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        else step_tick<T, DIRECT, PFP, GATE, 2>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+    } else {
+        step_tick<T, DIRECT, PFP, GATE, NT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
     }
 }
 
