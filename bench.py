@@ -184,10 +184,11 @@ def main():
     n_upd = sum(int(thm[(W + k) % T]) for k in range(K))
     bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * ekf.algorithmic_bytes(1)
     if mr_step:
-        # multirate correction tick per filter: read u6 + z8 + entry 136 + (step-1) stored samples (8 words each);
-        # write the corrected entry, step-1 replayed entries (136 each) and the new entry (144)
+        # multirate correction tick per filter (lazy history, k_step_mr): read u6 + z8 + the entry the measurement
+        # belongs to (136) + the (step-1) stored IMU samples in between (8 words each); write the corrected entry (136)
+        # and the newest entry (144).  The reference-shaped eager scheme also rewrote the step-1 entries in between.
         wsz = 4 if args.dtype == "f32" else 8
-        words = (6 + 8 + 136 + 8 * (mr_step - 1)) + (136 * mr_step + 144)
+        words = (6 + 8 + 136 + 8 * (mr_step - 1)) + (136 + 144)
         bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * words * wsz * B
     bad = ekf.count_nonfinite()
     # per-device error sums vs the generator's truth at the end of the resident sequence (cfg 5 reduction);

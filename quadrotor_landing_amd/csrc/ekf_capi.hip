@@ -185,6 +185,7 @@ struct qle_batch {
     bool mr = false;               // pub.multirate_ekf
     bool hist_dirty = true;        // state was overwritten: restart the history at the next tick
     int32_t* hist_first = nullptr; // [B] tick of each filter's oldest valid history entry
+    int32_t* fresh_from = nullptr; // [B] tick of the entry written by the filter's last correction tick (entries between are stale)
     double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
     double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
     double t_curr = 0.0, uniform_age = 0.0;
@@ -254,17 +255,18 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
     if (!p) return fail(QLE_ERR_INVALID, "params is null");
     qle_derived d;
     QLE_TRY(qle_params_derive(p, &d));
-    // State ring: C = 1 (single-rate) or largest reachable step delay + 1 (multirate, EKF.cpp:199-201).
+    // State ring: C = 1 (single-rate) or 2 x the largest reachable step delay + 1 (multirate, EKF.cpp:199-201).
     // Allocate first; the handle's parameters change only once everything needed exists.
     const bool mr = p->multirate_ekf != 0;
     int32_t C = 1;
     if (mr) {
         int32_t step_max = d.measurement_step_delay;
         if (p->dynamic_meas_delay) step_max = std::max((int32_t)(p->measurement_delay_max / d.dT_nom + 0.5), 1);
-        C = step_max + 1;
+        C = 2 * step_max + 1;   // lazy history (k_step_mr): a measurement in a stale zone restarts from the entry before it
     }
     if (mr && !h->hist_first) {
         hipError_t e = hipMalloc((void**)&h->hist_first, sizeof(int32_t) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&h->fresh_from, sizeof(int32_t) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMalloc((void**)&h->stamp, sizeof(double) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMalloc((void**)&h->delay_cur, sizeof(double) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMemsetAsync(h->delay_cur, 0, sizeof(double) * (size_t)h->Bp, h->stream);
@@ -302,7 +304,7 @@ extern "C" int qle_destroy(qle_batch* h)
     if (!h) return QLE_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->ring, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->hist_first, h->stamp,
+    void* bufs[] = {h->ring, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->hist_first, h->fresh_from, h->stamp,
                     h->delay_cur};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
@@ -575,6 +577,7 @@ static int mr_prepare(qle_batch* h)
 {
     if (h->mr && h->hist_dirty) {
         hipLaunchKernelGGL(k_fill_i32, grid_for(h, 256), dim3(256), 0, h->stream, h->hist_first, (int32_t)(h->tick - 1), h->B);
+        hipLaunchKernelGGL(k_fill_i32, grid_for(h, 256), dim3(256), 0, h->stream, h->fresh_from, (int32_t)(h->tick - 1), h->B);
         HIP_TRY(hipGetLastError());
     }
     h->hist_dirty = false;
@@ -714,7 +717,7 @@ static int launch_step_mr(qle_batch* h, const void* u, const void* z)
     T *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
-#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
+#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->fresh_from, h->last_corr, h->flags, h->delay_cur, h->B)
     if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
     else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
 #undef QLE_MR_LAUNCH
@@ -759,7 +762,7 @@ static int advance_tick(qle_batch* h)
         const int64_t C = h->C > 0 ? h->C : 1;
         const int64_t shift = ((h->rebase_at / 2) / C) * C;  // a multiple of C: ring slots (tick % C) are unchanged
         if (shift <= 0) return QLE_OK;
-        int32_t* arrs[2] = {h->last_corr, h->hist_first};
+        int32_t* arrs[3] = {h->last_corr, h->hist_first, h->fresh_from};
         for (int32_t* a : arrs)
             if (a) {
                 hipLaunchKernelGGL(k_rebase_ticks, grid_for(h, 256), dim3(256), 0, h->stream, a, (int32_t)shift, h->B);

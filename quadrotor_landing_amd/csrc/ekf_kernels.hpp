@@ -432,7 +432,7 @@ template <typename T, bool DIRECT, bool PFP>
 __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* ring, const T* __restrict__ us,
                                                     const T* __restrict__ zs, const T* __restrict__ pfp, const double* __restrict__ stamp,
                                                     T* __restrict__ aux_accel, T* __restrict__ aux_obs, int32_t* __restrict__ hist_first,
-                                                    int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, double* __restrict__ delay_out,
+                                                    int32_t* __restrict__ fresh_from, int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, double* __restrict__ delay_out,
                                                     int64_t B)
 {
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
@@ -456,7 +456,15 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         if (ok) last_corr[i] = gp.tick;
         flags[i] = (uint8_t)((ok ? 1 : 0) | (consume ? 2 : 0));
     }
-    int32_t base = m.tick - 1;  // entry the loop starts from; iterations run base+1 .. n
+    // Lazy history.  The reference re-predicts from the corrected entry to now and REWRITES every history entry on
+    // the way (EKF.cpp:222-226).  Those rewritten entries are read again only if a later measurement belongs to one of
+    // them, so here only the corrected entry and the newest one are written; the entries in between stay stale and
+    // are recomputed from the corrected entry (same arithmetic, same stored IMU samples -> same values) if that
+    // happens.  Per filter: hist_first = tick of the corrected (oldest valid) entry, fresh_from = tick of the entry
+    // written by that correction tick; entries strictly between the two are stale, everything from fresh_from on
+    // is the predict chain built on it.  A measurement tick mt in the stale zone starts from hist_first, so the ring
+    // holds 2 * step_max + 1 entries (qle_set_params).
+    int32_t start = m.tick - 1, mt = 0;    // entry the chain starts from; tick the measurement belongs to (if corr)
     if (corr) {
         // EKF.cpp:199-201: delay -> step delay -> history entry the measurement belongs to
         int32_t step = m.fixed_step;
@@ -467,33 +475,41 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
             step = (int32_t)(dcur / m.dT + 0.5);
             if (step < 1) step = 1;
         }
-        int32_t len = m.tick - hist_first[i];  // entries hist_first .. n-1
+        const int32_t first = hist_first[i];
+        int32_t len = m.tick - first;          // entries hist_first .. n-1
         if (len > m.C) len = m.C;              // older ones have been overwritten and are unreachable
         int32_t ind = len - step;
         if (ind < 0) ind = 0;
-        base = (m.tick - len) + ind;           // tick_m
-        hist_first[i] = base;                  // EKF.cpp:214-219
-        T* sm = ring_slot(ring, m, base);
-        load_rec<T, kSW, 0, kXW>(sm, i, x);
-        load_rec<T, kSW, kXW, kPW>(sm, i, P);
-        const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-        ekf_update<T, DIRECT>(p, nz, x, P, z, obs);          // EKF.cpp:209
-        store_rec<T, kSW, 0, kXW>(sm, i, x);                  // EKF.cpp:210-211
-        store_rec<T, kSW, kXW, kPW>(sm, i, P);
-    } else {
-        const T* sp = ring_slot(ring, m, base);
+        mt = (m.tick - len) + ind;
+        start = (mt > first && mt < fresh_from[i]) ? first : mt;
+        hist_first[i] = mt;                    // EKF.cpp:214-219
+        fresh_from[i] = m.tick;
+    }
+    {
+        const T* sp = ring_slot(ring, m, start);
         load_rec<T, kSW, 0, kXW>(sp, i, x);
         load_rec<T, kSW, kXW, kPW>(sp, i, P);
     }
-    for (int32_t t = base + 1; t <= m.tick; ++t) {            // EKF.cpp:222-226, then :249
+    for (int32_t t = start;; ) {
+        if (corr && t == mt) {                                // the entry the measurement belongs to
+            const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+            ekf_update<T, DIRECT>(p, nz, x, P, z, obs);      // EKF.cpp:209
+            T* sm = ring_slot(ring, m, t);
+            store_rec<T, kSW, 0, kXW>(sm, i, x);              // EKF.cpp:210-211
+            store_rec<T, kSW, kXW, kPW>(sm, i, P);
+        }
+        if (t == m.tick) break;
+        ++t;                                                  // EKF.cpp:222-226, then :249
         T* sk = ring_slot(ring, m, t);
         T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
         if (t != m.tick) load_rec<T, kSW, kUoff, 8>(sk, i, uk);
         const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
         ekf_predict<T>(p, nz, x, P, u6, accel);
-        store_rec<T, kSW, 0, kXW>(sk, i, x);
-        store_rec<T, kSW, kXW, kPW>(sk, i, P);
-        if (t == m.tick) store_rec<T, kSW, kUoff, 8>(sk, i, uk);  // EKF.cpp:254-256
+        if (t == m.tick) {
+            store_rec<T, kSW, 0, kXW>(sk, i, x);
+            store_rec<T, kSW, kXW, kPW>(sk, i, P);
+            store_rec<T, kSW, kUoff, 8>(sk, i, uk);           // EKF.cpp:254-256
+        }
     }
     if (aux_accel) {
 #pragma unroll
