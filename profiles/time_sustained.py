@@ -21,6 +21,8 @@ B = int(sys.argv[1])
 mixed = sys.argv[2] == "mixed"
 ekf = qla.BatchedRelativePoseEKF(B, "f32", **CFG3)
 T = max(140, int(4200 * 65536 / B) // 14 * 14)         # about 6 GB of inputs, whole measurement periods
+if os.environ.get("QLE_SEQ_TICKS"):
+    T = int(os.environ["QLE_SEQ_TICKS"])               # e.g. 14: inputs small enough to stay cached
 thm = np.zeros(T, np.uint8)
 if mixed:
     thm[13::14] = 1
