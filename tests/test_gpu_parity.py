@@ -611,6 +611,68 @@ def test_multirate_lazy_history_over_ring_wraps(dtype="f64"):
              limit_measurement_freq=0, **HW_TAGS), dtype, T=260, loosen=100.0)   # free run: rounding accumulates with the tick count
 
 
+@pytest.mark.parametrize("est_bias", [1, 0])
+@pytest.mark.parametrize("direct", [0, 1])
+def test_multirate_with_per_filter_parameters_and_conventional_method(direct, est_bias):
+    """The kernel instantiations the other multirate tests do not reach: k_step_mr / k_predict<MR> with the
+    conventional orientation method (EKF.cpp:440-444,455-458), per-filter noise and static-bias records (cfg 5) and
+    9 error states, fp64, every filter against its own oracle filter object on every tick."""
+    kw = dict(update_freq=100.0, direct_orien_method=direct, est_bias=est_bias, multirate_ekf=1, dynamic_meas_delay=1,
+              measurement_delay=0.030, measurement_delay_max=0.200, dyn_measurement_delay_offset=0.005,
+              limit_measurement_freq=1, measurement_freq=30.0, corner_margin_enbl=0)
+    po, pq = both(**kw)
+    rng = np.random.default_rng(2025)
+    B, T = 16, 90
+    pfp = np.zeros((B, 24))
+    pfp[:, 0:12] = np.array(list(po.Q)) * 10 ** rng.uniform(-0.5, 0.5, size=(B, 4)).repeat(3, axis=1)
+    pfp[:, 12:15] = rng.normal(size=(B, 3)) * 0.1
+    pfp[:, 15:18] = rng.normal(size=(B, 3)) * 0.01
+    pfp[:, 18:24] = np.array(list(po.R)) * rng.uniform(0.5, 2.0, size=(B, 6))
+    z0 = np.zeros((B, 7))
+    z0[:, 0:2] = rng.normal(size=(B, 2)) * 0.1; z0[:, 2] = rng.uniform(0.8, 2.0, size=B)
+    z0[:, 3:7] = np.array([0.7071067811865476, -0.7071067811865476, 0.0, 0.0])
+    ekf = qla.BatchedRelativePoseEKF(B, "f64", params=pq)
+    ekf.set_filter_params(pfp)
+    ekf.enable_gating(True)
+    ekf.initialize_state(z0, reinit_bias=True)
+    filt = []
+    for i in range(B):
+        q = pfp[i, 0:12]
+        pi = oracle.make_params(**dict(kw, Q_a=q[0:3], Q_w=q[3:6], Q_ab=q[6:9], Q_wb=q[9:12], ab_static=pfp[i, 12:15], wb_static=pfp[i, 15:18],
+                                       R_r=pfp[i, 18:21], R_ang=pfp[i, 21:24]))
+        f = oracle.Filter(pi)
+        f.set_apriltag(z0[i, :3], z0[i, 3:], -1.0)
+        f.f.measurement_ready = 0
+        filt.append(f)
+    pending = np.zeros(B, np.uint8)
+    zlast = z0.copy(); stamp = np.zeros(B)
+    n_perf = 0
+    for t in range(T):
+        tc = 0.01 * t
+        u = rand_imu(rng, B) * np.array([0.05, 0.05, 1, 0.2, 0.2, 0.2])
+        new = rng.uniform(size=B) < 0.35
+        xs = ekf.get_state()[0]
+        znew = meas_near(rng, po, xs, ang=0.2, pos=0.05)
+        zlast[new] = znew[new]
+        stamp[new] = tc - rng.uniform(0.0, 0.25, size=int(new.sum()))
+        pending |= new.astype(np.uint8)
+        for i in range(B):
+            filt[i].set_imu(u[i, :3], u[i, 3:])
+            if new[i]:
+                filt[i].set_apriltag(zlast[i, :3], zlast[i, 3:], stamp[i])
+            filt[i].filter_update(tc)
+        ekf.filter_update(u, zlast if pending.any() else None, pending if pending.any() else None, t_curr=tc, apriltag_time=stamp)
+        perf, cons, upds = ekf.tick_flags()
+        np.testing.assert_array_equal(perf, np.array([f.f.performed_correction for f in filt], np.uint8))
+        pending &= (1 - cons)
+        n_perf += int(perf.sum())
+        xg, Pg = ekf.get_state()
+        xr = np.stack([f.x() for f in filt]); Pr = np.stack([f.P() for f in filt])
+        assert_state_close(xg, Pg, xr, Pr, 1e-9, 1e-11, 1e-9)
+    assert n_perf > B
+    ekf.close()
+
+
 # ------------------------------------------------------ API robustness
 def test_api_round_trips_and_error_paths():
     pq = qla.make_params()
