@@ -733,12 +733,26 @@ def test_api_round_trips_and_error_paths():
 
 # ------------------------------------ on-chip-resident multi-tick variant
 @pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 5e-3)])
-def test_run_resident_matches_per_tick_path_and_oracle(dtype, tol):
+@pytest.mark.parametrize("variant", ["direct", "conventional_per_filter_params"])
+def test_run_resident_matches_per_tick_path_and_oracle(dtype, tol, variant):
     kw = golden_kwargs("rotors400")
+    pfp = None
+    if variant != "direct":
+        kw = dict(kw, direct_orien_method=0)
     po, pq = both(**kw)
     B, T = 300, 84
     thm = np.zeros(T, np.uint8); thm[13::14] = 1
     a = qla.BatchedRelativePoseEKF(B, dtype, params=pq)
+    if variant != "direct":   # k_step / k_predict / k_run_resident with the per-filter parameter record (cfg 5)
+        r5 = np.random.default_rng(5)
+        pfp = np.zeros((B, 24))
+        pfp[:, 0:12] = np.array(list(po.Q)) * 10 ** r5.uniform(-0.5, 0.5, size=(B, 4)).repeat(3, axis=1)
+        pfp[:, 12:15] = r5.normal(size=(B, 3)) * 0.1
+        pfp[:, 15:18] = r5.normal(size=(B, 3)) * 0.01
+        pfp[:, 18:24] = np.array(list(po.R)) * r5.uniform(0.5, 2.0, size=(B, 6))
+        if dtype == "f32":
+            pfp = pfp.astype(np.float32).astype(np.float64)
+        a.set_filter_params(pfp)
     seq = a.make_inputs(T, thm)
     a.synth_generate(seq, seed=11)
     # give the masks some structure: a third of the filters skip each measurement
@@ -756,7 +770,7 @@ def test_run_resident_matches_per_tick_path_and_oracle(dtype, tol):
     U = np.empty((T, B, 6)); Z = np.zeros((T, B, 7)); M = np.zeros((T, B), np.uint8)
     for t in range(T):
         U[t], Z[t], M[t] = seq.download_tick(t)
-    xr, Pr = oracle.run_batch(po, x0, P0, U, Z, M)
+    xr, Pr = oracle.run_batch(po, x0, P0, U, Z, M, per_filter_params=pfp)
     for xg, Pg in ((xa, Pa), (xb, Pb)):
         assert quat_err(xg[:, 6:10], xr[:, 6:10]) < tol
         keep = [i for i in range(16) if not 6 <= i < 10]
