@@ -611,13 +611,15 @@ def test_multirate_lazy_history_over_ring_wraps(dtype="f64"):
              limit_measurement_freq=0, **HW_TAGS), dtype, T=260, loosen=100.0)   # free run: rounding accumulates with the tick count
 
 
+@pytest.mark.parametrize("mr", [1, 0])
 @pytest.mark.parametrize("est_bias", [1, 0])
 @pytest.mark.parametrize("direct", [0, 1])
-def test_multirate_with_per_filter_parameters_and_conventional_method(direct, est_bias):
+def test_multirate_with_per_filter_parameters_and_conventional_method(direct, est_bias, mr):
     """The kernel instantiations the other multirate tests do not reach: k_step_mr / k_predict<MR> with the
     conventional orientation method (EKF.cpp:440-444,455-458), per-filter noise and static-bias records (cfg 5) and
-    9 error states, fp64, every filter against its own oracle filter object on every tick."""
-    kw = dict(update_freq=100.0, direct_orien_method=direct, est_bias=est_bias, multirate_ekf=1, dynamic_meas_delay=1,
+    9 error states, fp64, every filter against its own oracle filter object on every tick.  mr = 0: the same through
+    the single-rate fused tick with the decision logic on the device (k_step<..., PFP, GATE>)."""
+    kw = dict(update_freq=100.0, direct_orien_method=direct, est_bias=est_bias, multirate_ekf=mr, dynamic_meas_delay=1,
               measurement_delay=0.030, measurement_delay_max=0.200, dyn_measurement_delay_offset=0.005,
               limit_measurement_freq=1, measurement_freq=30.0, corner_margin_enbl=0)
     po, pq = both(**kw)
