@@ -511,10 +511,13 @@ __device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const 
 // ------------------------------------------------------------------- update
 // correction_step, EKF.cpp:417-502.  z = [r_c_tc(3), q_ct(x,y,z,w)(4)].
 // obs receives r_t_vt_obs(3), q_tv_obs(4) (members written at EKF.cpp:431-443).
-template <typename T, bool DIRECT>
-__device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
-                                           const T (&z)[7], T (&obs)[7])
+// emit_obs(obs) is called as soon as the reported observation exists, before the six fusions, so that a
+// caller that only stores it does not keep seven more values alive through the register-critical part.
+template <typename T, bool DIRECT, typename EmitObs>
+__device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
+                                                const T (&z)[7], EmitObs&& emit_obs)
 {
+    T obs[7];
     T q[4] = {x[6], x[7], x[8], x[9]};
     T r[3] = {x[0], x[1], x[2]};
     T Cc[9];
@@ -546,6 +549,7 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
             dy[i] = ro - r[i];                               // EKF.cpp:447
         }
         obs[3] = qo[0]; obs[4] = qo[1]; obs[5] = qo[2]; obs[6] = qo[3];
+        emit_obs(obs);
         T qc[4] = {-q[0], -q[1], -q[2], q[3]}, dq[4], dth[3];
         quat_mul(qc, qo, dq);                                // EKF.cpp:448
         quat_norm(dq);                                       // EKF.cpp:449
@@ -624,7 +628,7 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
         }
     }
     // Six scalar updates (EKF.cpp:475-481 in sequential form): for component c
-    //   h = P g'_c^T, s = g'_c h + d_c, k = h/s, dx += k (y'_c - g'_c dx), P -= h k^T.
+    //   h = P g'_c^T, s = g'_c h + d_c, k = h/s, dx += k (y'_c - g'_c dx), P -= k h^T.
     T dx[15];
 #pragma unroll
     for (int k = 0; k < 15; ++k) dx[k] = T(0);
@@ -643,14 +647,16 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
 #pragma unroll
         for (int m = 0; m < 6; ++m)
             if (!DIRECT || m <= c) { s += Gm[c][m] * h[J[m]]; nu -= Gm[c][m] * dx[J[m]]; }
+        // gain k = h / s is never stored: dx += h (nu/s), P(i,k) -= (h_i/s) h_k
         const T inv = T(1) / s;
-        T kk[15];
+        const T c_nu = inv * nu;
 #pragma unroll
-        for (int k = 0; k < 15; ++k) { kk[k] = h[k] * inv; dx[k] += kk[k] * nu; }
+        for (int k = 0; k < 15; ++k) dx[k] += h[k] * c_nu;
 #pragma unroll
         for (int i = 0; i < 15; ++i) {
+            const T hi = h[i] * inv;
 #pragma unroll
-            for (int k = i; k < 15; ++k) QLE_PS(i, k) -= h[i] * kk[k];
+            for (int k = i; k < 15; ++k) QLE_PS(i, k) -= hi * h[k];
         }
     }
 
@@ -667,6 +673,16 @@ __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>
         x[13 + i] = p.bias_on * (x[13 + i] + dx[12 + i]);
     }
     x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+}
+
+template <typename T, bool DIRECT>
+__device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
+                                           const T (&z)[7], T (&obs)[7])
+{
+    ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&o)[7]) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) obs[k] = o[k];
+    });
 }
 
 }  // namespace qle

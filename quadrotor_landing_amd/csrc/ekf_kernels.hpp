@@ -357,21 +357,21 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
     ekf_predict_levels<T>(p, nz, x, Po, u, accel, P, [](int) {});
-    T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
+    if (aux_accel) {  // optional side outputs (wave-uniform), written as soon as they exist
+#pragma unroll
+        for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
+    }
     if (corr) {
         T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-        ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
+        ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&obs)[7]) {
+            if (aux_accel) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
+            }
+        });
     }
     store_rec<T, kSW, 0, kXW, NT>(st, i, x);
     store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
-    if (aux_accel) {  // optional side outputs (wave-uniform)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
-        if (corr) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
-        }
-    }
 }
 
 template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
@@ -438,7 +438,6 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], accel[3] = {T(0), T(0), T(0)};
-    T obs[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
     load_rec<T, kUW, 0, kUW>(us, i, u);
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
@@ -493,7 +492,12 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     for (int32_t t = start;; ) {
         if (corr && t == mt) {                                // the entry the measurement belongs to
             const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-            ekf_update<T, DIRECT>(p, nz, x, P, z, obs);      // EKF.cpp:209
+            ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&o)[7]) {   // EKF.cpp:209
+                if (aux_accel) {
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
+                }
+            });
             T* sm = ring_slot(ring, m, t);
             store_rec<T, kSW, 0, kXW>(sm, i, x);              // EKF.cpp:210-211
             store_rec<T, kSW, kXW, kPW>(sm, i, P);
@@ -514,10 +518,6 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     if (aux_accel) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
-        if (corr) {
-#pragma unroll
-            for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
-        }
     }
 }
 
@@ -554,8 +554,7 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
         ekf_predict<T>(p, nz, x, P, u, accel);
         if (s >= 0 && zr[7] != T(0)) {
             const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-            T obs[7];
-            ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
+            ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [](const T (&)[7]) {});
         }
 #pragma unroll
         for (int c = 0; c < kUW; ++c) u[c] = un[c];
