@@ -127,6 +127,10 @@ int qle_set_params(qle_batch *h, const qle_params *p);
 /* Per-filter overrides of Q, static biases and R (BASELINE cfg 5):
  * pfp = [batch][QLE_PFP_DIM] or NULL to return to the shared parameters. */
 int qle_set_filter_params(qle_batch *h, const double *pfp);
+/* Read the per-filter overrides back ([batch][QLE_PFP_DIM], in the compute dtype's rounding): what
+ * qle_set_filter_params stored or what qle_synth_generate drew with perturb_filter_params (BASELINE cfg 5), so that
+ * a checker can run the same population. */
+int qle_get_filter_params(qle_batch *h, double *pfp);
 int64_t qle_batch_size(const qle_batch *h);
 int32_t qle_dtype(const qle_batch *h);
 int32_t qle_num_states(const qle_batch *h);
@@ -140,6 +144,15 @@ int qle_get_state(qle_batch *h, double *x, double *P);
 /* RelativePoseEKF::initialize_state(reinit_bias), EKF.cpp:305-344, batched:
  * seeds every filter from its own first tag pose z = [batch][7]. */
 int qle_initialize_state(qle_batch *h, const double *z, int32_t reinit_bias);
+/* The same for the filters with mask[i] != 0 only (mask NULL = all).  The reference keeps state_initialized per
+ * filter object: filter_update returns at once while it is false (EKF.cpp:129-130) and the node seeds a filter from
+ * ITS first detection (NODE.cpp:169-174).  Here a filter is "not initialised" until initialize_state / set_state has
+ * written its state (its stored quaternion is all zero until then); every tick entry point leaves such filters
+ * untouched -- no predict, no counter, no history entry -- and a filter seeded later starts with
+ * upds_since_correction = 0 (EKF.cpp:77) and a one-entry history (EKF.cpp:337-339). */
+int qle_initialize_state_masked(qle_batch *h, const double *z, const uint8_t *mask, int32_t reinit_bias);
+/* state_initialized (EKF.hpp:125) of every filter: [batch]. */
+int qle_get_state_initialized(qle_batch *h, uint8_t *state_initialized);
 /* Side outputs of the last tick: accel_rel (EKF.hpp:49; [batch][3]) and the
  * reported observation r_t_vt_obs,q_tv_obs (EKF.hpp:58-59; [batch][7]).
  * Only maintained while aux output is enabled (costs extra HBM writes). */
@@ -234,6 +247,9 @@ int qle_synth_generate(qle_batch *h, qle_inputs *in, const qle_synth_cfg *c);
 /* Per-device error sums against the generator's truth at the end of the
  * sequence: out = { sum |r_err|^2, sum |theta_err|^2, count } (cfg 5). */
 int qle_synth_rmse(qle_batch *h, const qle_inputs *in, double out[3]);
+/* The generator's truth at the end of the sequence: pose = [batch][7] (r, q xyzw), imu_bias = [batch][6] (accel, gyro
+ * bias).  Either pointer may be NULL.  Lets a host computation check qle_synth_rmse and the filters' tracking. */
+int qle_synth_get_truth(qle_batch *h, const qle_inputs *in, double *pose, double *imu_bias);
 
 /* ---- reporting (what the node publishes after a tick, NODE.cpp:192-220) ---- */
 /* pose = [batch][7] (r, q xyzw); pose_cov = [batch][36]: rows/cols {0-2,6-8} of

@@ -67,7 +67,8 @@ def build(force=False):
 
 
 def build_structured(force=False):
-    src = [os.path.join(_HERE, "ekf_structured_cpu.cpp"), os.path.join(_HERE, "..", "quadrotor_landing_amd", "csrc", "ekf_device.hpp")]
+    src = [os.path.join(_HERE, "ekf_structured_cpu.cpp"), os.path.join(_HERE, "..", "quadrotor_landing_amd", "csrc", "ekf_device.hpp"),
+           os.path.join(_HERE, "..", "quadrotor_landing_amd", "csrc", "ekf_quad.hpp")]
     stale = (not os.path.exists(_LIB_STRUCT)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_STRUCT) for s in src)
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B", "libekf_oracle_structured.so"], check=True)
@@ -77,9 +78,7 @@ def build_structured(force=False):
 _slib = None
 
 
-def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True, n_threads=0):
-    """The engine's own per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_device.hpp) compiled for the CPU:
-    same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product."""
+def _structured_lib():
     global _slib
     if _slib is None:
         build_structured()
@@ -87,6 +86,35 @@ def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True
         _slib.orc_structured_run_batch.argtypes = [C.POINTER(OrcParams), C.c_int64, C.c_int64, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
                                                    C.POINTER(_d), C.POINTER(C.c_uint8), _i, _i, _i]
         _slib.orc_structured_run_batch.restype = C.c_int64
+        _slib.orc_quad_run_batch.argtypes = [C.POINTER(OrcParams), C.c_int64, C.c_int64, C.POINTER(_d), C.POINTER(_d), C.POINTER(_d),
+                                             C.POINTER(_d), C.POINTER(C.c_uint8), _i]
+        _slib.orc_quad_run_batch.restype = C.c_int64
+    return _slib
+
+
+def quad_run_batch(p, x, P, u, z=None, mask=None, dtype="f64"):
+    """The engine's four-lanes-per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_quad.hpp) on an emulated quad:
+    same contract as run_batch.  No-GPU algebra check of the quad kernels; never part of the product."""
+    L = _structured_lib()
+    n = p.num_states
+    x = np.array(x, dtype=np.float64, order="C").reshape(-1, 16)
+    B = x.shape[0]
+    P = np.array(P, dtype=np.float64, order="C").reshape(B, n * n)
+    u = np.ascontiguousarray(u, dtype=np.float64).reshape(-1, B, 6)
+    T = u.shape[0]
+    zp = mp = None
+    if mask is not None:
+        z = np.ascontiguousarray(z, dtype=np.float64).reshape(T, B, 7)
+        mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(T, B)
+        zp = _p(z); mp = mask.ctypes.data_as(C.POINTER(C.c_uint8))
+    L.orc_quad_run_batch(C.byref(p), B, T, _p(x), _p(P), _p(u), zp, mp, 0 if dtype == "f32" else 1)
+    return x, P.reshape(B, n, n)
+
+
+def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True, n_threads=0):
+    """The engine's own per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_device.hpp) compiled for the CPU:
+    same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product."""
+    _slib = _structured_lib()
     n = p.num_states
     x = np.array(x, dtype=np.float64, order="C").reshape(-1, 16)
     B = x.shape[0]

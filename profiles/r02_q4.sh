@@ -1,0 +1,12 @@
+set -e
+mkdir -p gpurun_out/r2
+L=gpurun_out/r2/q4.log
+: > $L
+for lib in _w42; do
+for a in "65536 f32" "262144 f32" "4096 f32"; do
+  for q in 1 3; do
+    QLE_LIB=$PWD/quadrotor_landing_amd/libqle_ekf$lib.so QLE_QUAD=$q QLE_ROWS_MAX=0 timeout -k 10 200 python profiles/time_kernels.py $a >> $L 2>&1
+  done
+done
+done
+echo done >> $L

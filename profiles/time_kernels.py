@@ -1,5 +1,9 @@
 #!/usr/bin/env python3
-"""Per-kernel launch time of the hot kernels at B=65536 fp32 (HIP events, back-to-back launches)."""
+"""Per-kernel launch time of the hot kernels (HIP events, back-to-back launches): a tick whose tag record corrects every
+filter, one whose mask is all zero, and a predict-only tick.
+
+    [QLE_QUAD=0|1|2|3|7] [QLE_LIB=...] python profiles/time_kernels.py <batch> <f32|f64> [label]
+"""
 import json
 import os
 import sys
@@ -12,9 +16,10 @@ from bench import CFG3  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
-N = 300
-out = {"batch": B, "dtype": dtype}
-for name, mask_all in (("k_step_all_corrected", True), ("k_step_none_corrected", False)):
+N = int(os.environ.get("QLE_TIME_N", "300"))
+out = {"label": sys.argv[3] if len(sys.argv) > 3 else "", "batch": B, "dtype": dtype, "quad": os.environ.get("QLE_QUAD", "auto"),
+       "lib": os.path.basename(os.environ.get("QLE_LIB", "default"))}
+for name, mask_all in (("step_all_us", True), ("step_none_us", False)):
     ekf = qla.BatchedRelativePoseEKF(B, dtype, **CFG3)
     seq = ekf.make_inputs(14, np.ones(14, np.uint8))
     ekf.synth_generate(seq, seed=3)
@@ -24,12 +29,13 @@ for name, mask_all in (("k_step_all_corrected", True), ("k_step_none_corrected",
             seq.upload_tick(t, u, z, np.zeros(B, np.uint8))
     ekf.run(seq, 0, 28); ekf.synchronize()
     ekf.timer_begin(); ekf.run(seq, 0, N); ms = ekf.timer_end()
-    out[name + "_us"] = ms / N * 1e3
+    out[name] = round(ms / N * 1e3, 2)
+    out["bad_" + name[:-3]] = ekf.count_nonfinite()
     ekf.close()
 ekf = qla.BatchedRelativePoseEKF(B, dtype, **CFG3)
 seq = ekf.make_inputs(14, None)
 ekf.synth_generate(seq, seed=3)
 ekf.run(seq, 0, 28); ekf.synchronize()
 ekf.timer_begin(); ekf.run(seq, 0, N); ms = ekf.timer_end()
-out["k_predict_us"] = ms / N * 1e3
-print(json.dumps(out))
+out["predict_us"] = round(ms / N * 1e3, 2)
+print(json.dumps(out), flush=True)

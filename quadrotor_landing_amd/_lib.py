@@ -75,12 +75,15 @@ SYMBOLS = {
     "qle_destroy": (C.c_int, [_vp]),
     "qle_set_params": (C.c_int, [_vp, C.POINTER(QleParams)]),
     "qle_set_filter_params": (C.c_int, [_vp, _pd]),
+    "qle_get_filter_params": (C.c_int, [_vp, _pd]),
     "qle_batch_size": (_i64, [_vp]),
     "qle_dtype": (_i32, [_vp]),
     "qle_num_states": (_i32, [_vp]),
     "qle_set_state": (C.c_int, [_vp, _pd, _pd]),
     "qle_get_state": (C.c_int, [_vp, _pd, _pd]),
     "qle_initialize_state": (C.c_int, [_vp, _pd, _i32]),
+    "qle_initialize_state_masked": (C.c_int, [_vp, _pd, _pu8, _i32]),
+    "qle_get_state_initialized": (C.c_int, [_vp, _pu8]),
     "qle_enable_aux": (C.c_int, [_vp, _i32]),
     "qle_get_aux": (C.c_int, [_vp, _pd, _pd]),
     "qle_predict": (C.c_int, [_vp, _pd]),
@@ -101,6 +104,7 @@ SYMBOLS = {
     "qle_synth_cfg_default": (C.c_int, [C.POINTER(QleSynthCfg)]),
     "qle_synth_generate": (C.c_int, [_vp, _vp, C.POINTER(QleSynthCfg)]),
     "qle_synth_rmse": (C.c_int, [_vp, _vp, _pd]),
+    "qle_synth_get_truth": (C.c_int, [_vp, _vp, _pd, _pd]),
     "qle_get_report": (C.c_int, [_vp, _pd, _pd, _pd, _pd]),
     "qle_count_nonfinite": (C.c_int, [_vp, C.POINTER(_i64)]),
     "qle_synchronize": (C.c_int, [_vp]),

@@ -3,30 +3,13 @@
 // management, parameter derivation (initialize_params, EKF.cpp:87-125 of the
 // reference), AoS<->quad-row staging, launches on the handle's own stream.
 // There is deliberately no CPU compute path in this file.
-#include "../../include/qle_ekf.h"
-
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <new>
-#include <string>
-#include <vector>
-
-#include "ekf_kernels.hpp"
-#include "ekf_rows.hpp"
+#include "ekf_host.hpp"
 #include "synth_kernels.hpp"
-
-using namespace qle;
 
 // ------------------------------------------------------------------ errors
 static thread_local std::string g_err;
 
-static int fail(int code, const char* fmt, ...)
+int qle_fail(int code, const char* fmt, ...)
 {
     char buf[512];
     va_list ap;
@@ -36,24 +19,6 @@ static int fail(int code, const char* fmt, ...)
     g_err = buf;
     return code;
 }
-#define HIP_TRY(expr)                                                                          \
-    do {                                                                                       \
-        hipError_t e_ = (expr);                                                                \
-        if (e_ != hipSuccess) return fail(QLE_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
-    } while (0)
-#define QLE_TRY(expr)            \
-    do {                         \
-        int rc_ = (expr);        \
-        if (rc_ != QLE_OK) return rc_; \
-    } while (0)
-
-// Nothing may throw across the C ABI: entry points that allocate host memory run under this guard.
-#define QLE_GUARD_BEGIN try {
-#define QLE_GUARD_END                                                                   \
-    }                                                                                   \
-    catch (const std::bad_alloc&) { return fail(QLE_ERR_NOMEM, "host allocation failed"); } \
-    catch (const std::exception& e_) { return fail(QLE_ERR_INVALID, "unexpected exception: %s", e_.what()); } \
-    catch (...) { return fail(QLE_ERR_INVALID, "unexpected exception"); }
 
 extern "C" const char* qle_last_error(void) { return g_err.c_str(); }
 extern "C" const char* qle_version(void) { return "quadrotor_landing_amd 0.1 (gfx950)"; }
@@ -139,106 +104,6 @@ extern "C" int qle_params_derive(const qle_params* p, qle_derived* d)
     return QLE_OK;
 }
 
-// ------------------------------------------------------------------ handle
-struct qle_batch {
-    int64_t B = 0;
-    int32_t dtype = QLE_F32;
-    int32_t device = 0;
-    int32_t block = 256;
-    int32_t split = 0;        // nt == 3: which workgroups keep their tiles cached (cached_workgroup() in ekf_kernels.hpp)
-    int32_t nt_refresh = 0;   // > 0: nt == 1 and the state is <= 40 MiB: non-temporal stores, cached-store tick every nt_refresh ticks
-    int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal, 3 split
-    int64_t rows_max = 0;  // batches up to this size may use the rows-across-lanes kernel (ekf_rows.hpp)
-    bool rows_forced = false;  // QLE_ROWS_MAX set: use it for every eligible tick (tests, experiments)
-    size_t wsz = 4;
-    qle_params pub;
-    qle_derived der;
-    DevParams<float> pf;
-    DevParams<double> pd;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int64_t Bp = 0;        // batch padded to whole 64-filter tiles
-    // State storage: ring of C arrays of 144-word state records, slot = tick % C.  C = 1 for the
-    // single-rate filter (in place); C = max step delay + 1 for the multirate filter, where the
-    // ring is the history of EKF.hpp:62-64.  The state "now" is slot (tick-1) % C.
-    void* ring = nullptr;
-    int32_t C = 0;
-    void* pfp = nullptr;   // [24 words] per-filter params, wave tiles
-    bool pfp_on = false;
-    bool aux = false;
-    void* aux_accel = nullptr;  // AoS [B][3], compute dtype
-    void* aux_obs = nullptr;    // AoS [B][7]
-    void* tick_u = nullptr;     // one tick of inputs in device layout
-    void* tick_z = nullptr;
-    double* stage = nullptr;    // AoS fp64 staging, kStageFilters filters
-    uint8_t* stage_mask = nullptr;
-    unsigned long long* counter = nullptr;
-    bool state_set = false;
-    // device-side measurement gating (EKF.cpp:147-186)
-    bool gating = false;
-    int32_t* last_corr = nullptr;  // [B] index of each filter's last correcting tick, -1 = never
-    uint8_t* flags = nullptr;      // [B] bit0 performed_correction, bit1 measurement consumed (last measurement tick)
-    int64_t tick = 0;              // filter_update ticks executed so far (since the last origin shift)
-    int64_t tick_origin = 0;       // ticks removed by origin shifts (reporting only)
-    int64_t rebase_at = (int64_t)1 << 30;  // shift the tick origin when the counter reaches this (QLE_TICK_REBASE for tests)
-    // multirate EKF (EKF.cpp:196-236, 251-264)
-    bool mr = false;               // pub.multirate_ekf
-    bool hist_dirty = true;        // state was overwritten: restart the history at the next tick
-    int32_t* hist_first = nullptr; // [B] tick of each filter's oldest valid history entry
-    int32_t* fresh_from = nullptr; // [B] tick of the entry written by the filter's last correction tick (entries between are stale)
-    double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
-    double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
-    double t_curr = 0.0, uniform_age = 0.0;
-    bool have_stamps = false;
-};
-
-struct qle_inputs {
-    qle_batch* h = nullptr;  // owner; only dereferenced by calls that also take the handle or run before its destroy
-    int32_t device = 0;      // copied so that destroy never touches the (possibly already destroyed) handle
-    int64_t T = 0;
-    int64_t n_slots = 0;
-    std::vector<int32_t> slot;  // per tick: measurement slot or -1
-    size_t pitch_u = 0, pitch_z = 0;
-    void* u = nullptr;
-    void* z = nullptr;
-    void* truth = nullptr;      // AoS [B][7] fp64: r(3), q(4) at the end of the sequence
-    void* truth_bias = nullptr; // AoS [B][6] fp64
-    int32_t* d_slot = nullptr;  // the slot table on the device (qle_run_resident, generator)
-    bool has_truth = false;
-};
-
-static constexpr int64_t kStageFilters = 32768;
-static constexpr int64_t kStageDoubles = kStageFilters * 225;
-
-template <typename T> static DevParams<T> make_dev(const qle_params& p, const qle_derived& d)
-{
-    DevParams<T> o;
-    o.dT = (T)d.dT_nom;
-    o.dTw = p.est_bias ? (T)d.dT_nom : T(0);
-    o.bias_on = p.est_bias ? T(1) : T(0);
-    o.small_ang_tol = (T)p.small_ang_tol;
-    for (int i = 0; i < 3; ++i) { o.g[i] = (T)p.g[i]; o.r_v_cv[i] = (T)p.r_v_cv[i]; o.ab_static[i] = (T)p.ab_static[i]; o.wb_static[i] = (T)p.wb_static[i]; }
-    for (int i = 0; i < 4; ++i) o.q_vc[i] = (T)d.q_vc[i];
-    for (int i = 0; i < 9; ++i) o.C_vc[i] = (T)d.C_vc[i];
-    for (int i = 0; i < 12; ++i) o.Q[i] = (T)d.Q[i];
-    for (int i = 0; i < 6; ++i) o.R[i] = (T)d.R[i];
-    return o;
-}
-template <typename T> static const DevParams<T>& dev(const qle_batch* h);
-template <> const DevParams<float>& dev<float>(const qle_batch* h) { return h->pf; }
-template <> const DevParams<double>& dev<double>(const qle_batch* h) { return h->pd; }
-
-static inline dim3 grid_for(const qle_batch* h, int block) { return dim3((unsigned)((h->B + block - 1) / block)); }
-
-static inline size_t slot_bytes(const qle_batch* h) { return (size_t)kSW * (size_t)h->Bp * h->wsz; }
-static inline int32_t slot_of(const qle_batch* h, int64_t tick)
-{
-    int64_t s = tick % h->C;
-    return (int32_t)(s < 0 ? s + h->C : s);
-}
-// state after the last executed tick / state the next tick writes
-static inline void* state_cur(const qle_batch* h) { return (char*)h->ring + slot_bytes(h) * (size_t)slot_of(h, h->tick - 1); }
-static inline void* state_next(const qle_batch* h) { return (char*)h->ring + slot_bytes(h) * (size_t)slot_of(h, h->tick); }
 
 static int check_handle(const qle_batch* h)
 {
@@ -264,26 +129,34 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
         if (p->dynamic_meas_delay) step_max = std::max((int32_t)(p->measurement_delay_max / d.dT_nom + 0.5), 1);
         C = 2 * step_max + 1;   // lazy history (k_step_mr): a measurement in a stale zone restarts from the entry before it
     }
-    if (mr && !h->hist_first) {
-        hipError_t e = hipMalloc((void**)&h->hist_first, sizeof(int32_t) * (size_t)h->Bp);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->fresh_from, sizeof(int32_t) * (size_t)h->Bp);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->stamp, sizeof(double) * (size_t)h->Bp);
-        if (e == hipSuccess) e = hipMalloc((void**)&h->delay_cur, sizeof(double) * (size_t)h->Bp);
-        if (e == hipSuccess) e = hipMemsetAsync(h->delay_cur, 0, sizeof(double) * (size_t)h->Bp, h->stream);
-        if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "multirate bookkeeping arrays: %s", hipGetErrorString(e));
+    if (mr && !h->hist_first) {   // allocate everything into locals; the handle changes only when all of it exists
+        int32_t *hf = nullptr, *ff = nullptr;
+        double *stp = nullptr, *dc = nullptr;
+        hipError_t e = hipMalloc((void**)&hf, sizeof(int32_t) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&ff, sizeof(int32_t) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&stp, sizeof(double) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&dc, sizeof(double) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMemsetAsync(dc, 0, sizeof(double) * (size_t)h->Bp, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(stp, 0, sizeof(double) * (size_t)h->Bp, h->stream);
+        if (e != hipSuccess) {
+            void* tmp[] = {hf, ff, stp, dc};
+            for (void* b : tmp)
+                if (b) (void)hipFree(b);
+            return fail(QLE_ERR_NOMEM, "multirate bookkeeping arrays: %s", hipGetErrorString(e));
+        }
+        h->hist_first = hf; h->fresh_from = ff; h->stamp = stp; h->delay_cur = dc;
     }
     if (C != h->C) {
         void* nr = nullptr;
         hipError_t e = hipMalloc(&nr, slot_bytes(h) * (size_t)C);
         if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "hipMalloc of the state ring (%d slots x %lld filters): %s", C, (long long)h->Bp, hipGetErrorString(e));
-        if (h->ring) {  // keep the current state: it moves to the slot the new ring assigns to tick-1
+        e = hipMemsetAsync(nr, 0, slot_bytes(h) * (size_t)C, h->stream);   // all-zero records = filters not initialised
+        if (e == hipSuccess && h->ring) {  // keep the current state: it moves to the slot the new ring assigns to tick-1
             int64_t sn = (h->tick - 1) % C;
             if (sn < 0) sn += C;
             e = hipMemcpyAsync((char*)nr + slot_bytes(h) * (size_t)sn, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream);
             if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
             if (e == hipSuccess) e = hipFree(h->ring);
-        } else {
-            e = hipMemsetAsync(nr, 0, slot_bytes(h) * (size_t)C, h->stream);
         }
         if (e != hipSuccess) { (void)hipFree(nr); return fail(QLE_ERR_HIP, "state ring setup: %s", hipGetErrorString(e)); }
         h->ring = nr;
@@ -358,11 +231,13 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(3, std::max(0, std::atoi(s)));
         if (const char* s = std::getenv("QLE_SPLIT")) h->split = std::atoi(s);
     }
-    // Rows-across-lanes kernel (16 lanes per filter).  Measured (profiles/r01_tuning.md section 3): its per-wave
-    // instruction stream is as long as the one-lane-per-filter kernels', so it only pays where those spill:
-    // fp64 ticks that carry corrections, up to ~6k filters (BASELINE cfg 2: 15 vs 23 us per tick).
-    h->rows_max = dtype == QLE_F64 ? 6144 : 0;
-    if (const char* s = std::getenv("QLE_ROWS_MAX")) { h->rows_max = std::atoll(s); h->rows_forced = true; }
+    // Workgroup-cooperative tick kernel (ekf_quad_kernels.hpp: a scalar wave + covariance quads, 45 covariance values per lane).
+    // Measured (profiles/r02_tuning.md): it wins where the one-lane-per-filter kernel spills and the chip is not full -- fp64 ticks
+    // that carry corrections up to 16 384 filters (BASELINE cfg 2: 13.9 vs 18.9 us per tick at 4 096 filters) -- and loses elsewhere
+    // (fp32 at 65 536 filters 25 vs 14.7 us, fp64 60 vs 38 us), so it is selected only there.  QLE_QUAD=bits overrides
+    // (1: ticks with tag poses, 2: predict-only ticks, 0: never).
+    h->quad = (dtype == QLE_F64 && batch <= 16384) ? 1 : 0;
+    if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
     if (const char* s = std::getenv("QLE_TICK_REBASE")) {
         const long long v = std::atoll(s);
         if (v >= 16) h->rebase_at = v;
@@ -505,7 +380,6 @@ static int unpack_P(qle_batch* h, const void* src, double* P)
     return QLE_OK;
 }
 
-#define BY_DTYPE(h, FN, ...) ((h)->dtype == QLE_F32 ? FN<float>(__VA_ARGS__) : FN<double>(__VA_ARGS__))
 
 extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
 {
@@ -513,6 +387,10 @@ extern "C" int qle_set_state(qle_batch* h, const double* x, const double* P)
     if (!x || !P) return fail(QLE_ERR_INVALID, "x and P must be non-null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, x, kXW, kXW, state_cur(h), kSW, 0));
     QLE_TRY(BY_DTYPE(h, pack_P, h, P, state_cur(h)));
+    if (!h->state_set && h->last_corr) {   // first state of the handle: upds_since_correction = 0 now (EKF.cpp:77)
+        hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->last_corr, (int32_t)(h->tick - 1), h->B);
+        HIP_TRY(hipGetLastError());
+    }
     h->state_set = true;
     h->hist_dirty = true;
     return QLE_OK;
@@ -535,14 +413,29 @@ extern "C" int qle_set_filter_params(qle_batch* h, const double* pfp)
     return QLE_OK;
 }
 
+extern "C" int qle_get_filter_params(qle_batch* h, double* pfp)
+{
+    QLE_TRY(check_handle(h));
+    if (!pfp) return fail(QLE_ERR_INVALID, "pfp is null");
+    if (!h->pfp || !h->pfp_on) return fail(QLE_ERR_STATE, "no per-filter parameters are set (qle_set_filter_params, or qle_synth_generate with perturb_filter_params)");
+    return BY_DTYPE(h, unpack_rows, h, h->pfp, kFW, kFW, pfp, kFW, 0);
+}
+
 extern "C" int qle_enable_aux(qle_batch* h, int32_t on)
 {
     QLE_TRY(check_handle(h));
     if (on && !h->aux_accel) {
-        HIP_TRY(hipMalloc(&h->aux_accel, 3 * (size_t)h->B * h->wsz));
-        HIP_TRY(hipMalloc(&h->aux_obs, 7 * (size_t)h->B * h->wsz));
-        HIP_TRY(hipMemsetAsync(h->aux_accel, 0, 3 * (size_t)h->B * h->wsz, h->stream));
-        HIP_TRY(hipMemsetAsync(h->aux_obs, 0, 7 * (size_t)h->B * h->wsz, h->stream));
+        void *a = nullptr, *o = nullptr;
+        hipError_t e = hipMalloc(&a, 3 * (size_t)h->B * h->wsz);
+        if (e == hipSuccess) e = hipMalloc(&o, 7 * (size_t)h->B * h->wsz);
+        if (e == hipSuccess) e = hipMemsetAsync(a, 0, 3 * (size_t)h->B * h->wsz, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(o, 0, 7 * (size_t)h->B * h->wsz, h->stream);
+        if (e != hipSuccess) {
+            if (a) (void)hipFree(a);
+            if (o) (void)hipFree(o);
+            return fail(QLE_ERR_NOMEM, "side-output buffers: %s", hipGetErrorString(e));
+        }
+        h->aux_accel = a; h->aux_obs = o;
     }
     h->aux = on != 0;
     return QLE_OK;
@@ -573,184 +466,36 @@ extern "C" int qle_get_aux(qle_batch* h, double* accel_rel, double* obs)
 
 // -------------------------------------------------------------- hot launches
 // Restart the multirate history with the single entry "state now" (EKF.cpp:337-339).
-static int mr_prepare(qle_batch* h)
+int mr_prepare(qle_batch* h)
 {
     if (h->mr && h->hist_dirty) {
-        hipLaunchKernelGGL(k_fill_i32, grid_for(h, 256), dim3(256), 0, h->stream, h->hist_first, (int32_t)(h->tick - 1), h->B);
-        hipLaunchKernelGGL(k_fill_i32, grid_for(h, 256), dim3(256), 0, h->stream, h->fresh_from, (int32_t)(h->tick - 1), h->B);
+        hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->hist_first, (int32_t)(h->tick - 1), h->B);
+        hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->fresh_from, (int32_t)(h->tick - 1), h->B);
         HIP_TRY(hipGetLastError());
     }
     h->hist_dirty = false;
     return QLE_OK;
 }
 
-// The rows-across-lanes kernel covers the plain single-rate tick (no device gating, no multirate history,
-// no side outputs); everything else runs on the one-lane-per-filter kernels.
-static inline bool use_rows(const qle_batch* h, bool has_meas)
-{
-    return h->B <= h->rows_max && (has_meas || h->rows_forced) && !h->mr && !h->gating && !h->aux;
-}
-
-template <typename T>
-static int launch_rows(qle_batch* h, const void* u, const void* z)
-{
-    const DevParams<T>& p = dev<T>(h);
-    const int64_t lanes = h->B * kRowLanes;
-    const dim3 g((unsigned)((lanes + kBlock - 1) / kBlock)), b(kBlock);
-    const T* pfp = (const T*)h->pfp;
-#define QLE_ROWS(D, F) hipLaunchKernelGGL((k_rows<T, D, F>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)u, (const T*)z, pfp, h->B)
-    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_ROWS(true, true); else QLE_ROWS(true, false); }
-    else { if (h->pfp_on) QLE_ROWS(false, true); else QLE_ROWS(false, false); }
-#undef QLE_ROWS
-    HIP_TRY(hipGetLastError());
-    return QLE_OK;
-}
-
-// Kernel cache policy of this tick.  For an L2-sized state (h->nt == 1) the fastest sustained scheme measured
-// (profiles/r01_tuning.md section 5) is: non-temporal loads AND stores -- the stores update the lines the state
-// already has in the Infinity Cache and leave no dirty L2 to flush at the kernel boundary -- plus one tick with
-// cached stores every nt_refresh (128) ticks, which re-allocates the state in the Infinity Cache.  Without the refresh the
-// state drifts out of the cache within ~3 000 ticks and every tick streams from HBM (9.3 -> 10.9 us per predict
-// at 65 536 filters); cached stores on every tick cost 9.9 us.  QLE_REFRESH=R overrides (0: cached stores always).
-static inline int effective_nt(const qle_batch* h)
-{
-    if (h->nt == 1 && h->nt_refresh > 0) return (h->tick % h->nt_refresh) == 0 ? 1 : 2;
-    if (h->nt == 3 && h->mr) return 2;   // the split policy is for the in-place single-rate state
-    return h->nt;
-}
-
-// prediction_step from `src` into `dst`; keep_u: the record also stores the IMU sample (multirate history).
-template <typename T>
-static int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u)
-{
-    const DevParams<T>& p = dev<T>(h);
-    const dim3 g = grid_for(h, h->block), b(h->block);
-    T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
-    const T* pfp = (const T*)h->pfp;
-#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B, h->split)
-#define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
-    const int nt = effective_nt(h);
-#define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)
-    if (keep_u) QLE_PRED_M(true);
-    else if (nt == 3) QLE_PRED_N(3, false);
-    else QLE_PRED_M(false);
-#undef QLE_PRED_M
-#undef QLE_PRED_N
-#undef QLE_PRED
-    HIP_TRY(hipGetLastError());
-    return QLE_OK;
-}
 // the predict of one filter tick: slot n-1 -> slot n (the same slot when C == 1)
 template <typename T>
 static int launch_predict(qle_batch* h, const void* u)
 {
-    if (use_rows(h, false)) return launch_rows<T>(h, u, nullptr);
+    if (use_quad(h, 2)) return launch_quad<T>(h, u, nullptr);
     QLE_TRY(mr_prepare(h));
     return launch_predict_sd<T>(h, u, state_cur(h), state_next(h), h->mr);
 }
 
-static GateParams make_gate(const qle_batch* h)
-{
-    GateParams g;
-    std::memset(&g, 0, sizeof(g));
-    g.limit = h->pub.limit_measurement_freq;
-    g.upd_per_meas = h->der.upd_per_meas;
-    g.corner_enbl = h->pub.corner_margin_enbl;
-    g.n_tags = h->pub.n_tags;
-    g.tick = (int32_t)h->tick;
-    for (int i = 0; i < 9; ++i) g.K[i] = h->pub.camera_K[i];
-    const double m = h->pub.tag_in_view_margin;
-    g.x_lo = h->pub.camera_width * m;  g.x_hi = h->pub.camera_width * (1 - m);    // EKF.cpp:175-178
-    g.y_lo = h->pub.camera_height * m; g.y_hi = h->pub.camera_height * (1 - m);
-    for (int i = 0; i < QLE_MAX_TAGS; ++i) {
-        g.hw[i] = h->pub.tag_widths[i] / 2;
-        g.px[i] = h->pub.tag_positions[3 * i];
-        g.py[i] = h->pub.tag_positions[3 * i + 1];
-    }
-    return g;
-}
-
-template <typename T, bool DIRECT, bool GATE>
-static int launch_step_dg(qle_batch* h, const void* u, const void* z)
-{
-    const DevParams<T>& p = dev<T>(h);
-    const GateParams gp = make_gate(h);
-    const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
-    const T* pfp = (const T*)h->pfp;
-#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split)
-#define QLE_STEP_N(N) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N); else QLE_STEP_LAUNCH(false, N); } while (0)
-    const int nt = effective_nt(h);
-    if (nt == 3) QLE_STEP_N(3); else if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);
-#undef QLE_STEP_N
-#undef QLE_STEP_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return QLE_OK;
-}
-static MrParams make_mr(const qle_batch* h)
-{
-    MrParams m;
-    std::memset(&m, 0, sizeof(m));
-    m.C = h->C;
-    m.tick = (int32_t)h->tick;
-    m.fixed_step = h->der.measurement_step_delay;
-    m.dynamic = h->pub.dynamic_meas_delay;
-    m.gate = h->gating ? 1 : 0;
-    m.slot_words = (int64_t)kSW * h->Bp;
-    m.dT = h->der.dT_nom;
-    m.offset = h->pub.dyn_measurement_delay_offset;
-    m.delay_max = h->pub.measurement_delay_max;
-    m.t_curr = h->t_curr;
-    m.uniform_age = h->uniform_age;
-    return m;
-}
-
-// One multirate tick that carries tag poses (predict-only multirate ticks go through launch_predict).
-template <typename T>
-static int launch_step_mr(qle_batch* h, const void* u, const void* z)
-{
-    QLE_TRY(mr_prepare(h));
-    const DevParams<T>& p = dev<T>(h);
-    const GateParams gp = make_gate(h);
-    const MrParams m = make_mr(h);
-    const dim3 g = grid_for(h, h->block), b(h->block);
-    T *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
-    const T* pfp = (const T*)h->pfp;
-    const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
-#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->fresh_from, h->last_corr, h->flags, h->delay_cur, h->B)
-    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
-    else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
-#undef QLE_MR_LAUNCH
-    HIP_TRY(hipGetLastError());
-    return QLE_OK;
-}
 
 template <typename T>
 static int launch_step(qle_batch* h, const void* u, const void* z)
 {
-    if (use_rows(h, true)) return launch_rows<T>(h, u, z);
+    if (h->gating) h->flags_tick = h->tick;   // this tick writes the per-filter flag bytes (gated kernels only)
+    if (use_quad(h, 1)) return launch_quad<T>(h, u, z);
     if (h->mr) return launch_step_mr<T>(h, u, z);
-    if (h->pub.direct_orien_method) return h->gating ? launch_step_dg<T, true, true>(h, u, z) : launch_step_dg<T, true, false>(h, u, z);
-    return h->gating ? launch_step_dg<T, false, true>(h, u, z) : launch_step_dg<T, false, false>(h, u, z);
+    return launch_step_lane<T>(h, u, z);
 }
 
-template <typename T, bool DIRECT>
-static int launch_update_d(qle_batch* h, const void* z)
-{
-    const DevParams<T>& p = dev<T>(h);
-    const dim3 g = grid_for(h, h->block), b(h->block);
-    T *st = (T*)state_cur(h), *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
-    const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on) hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-    else hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-    HIP_TRY(hipGetLastError());
-    return QLE_OK;
-}
-template <typename T>
-static int launch_update(qle_batch* h, const void* z)
-{
-    return h->pub.direct_orien_method ? launch_update_d<T, true>(h, z) : launch_update_d<T, false>(h, z);
-}
 
 // One filter_update tick has been launched.  Tick indices are 32-bit on the device
 // (last_corr, ring slot = tick % C); long before they could wrap, shift the origin by a
@@ -765,10 +510,11 @@ static int advance_tick(qle_batch* h)
         int32_t* arrs[3] = {h->last_corr, h->hist_first, h->fresh_from};
         for (int32_t* a : arrs)
             if (a) {
-                hipLaunchKernelGGL(k_rebase_ticks, grid_for(h, 256), dim3(256), 0, h->stream, a, (int32_t)shift, h->B);
+                hipLaunchKernelGGL(k_rebase_ticks<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, a, (int32_t)shift, h->B);
                 HIP_TRY(hipGetLastError());
             }
         h->tick -= shift;
+        h->flags_tick -= shift;
         h->tick_origin += shift;
     }
     return QLE_OK;
@@ -787,6 +533,7 @@ extern "C" int qle_predict(qle_batch* h, const double* u)
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     h->hist_dirty = true;  // a bare prediction_step is not a filter tick: the multirate history restarts
+    if (h->quad & 2) return BY_DTYPE(h, launch_quad, h, h->tick_u, nullptr);
     return BY_DTYPE(h, launch_predict_sd, h, h->tick_u, state_cur(h), state_cur(h), false);
 }
 extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)
@@ -818,10 +565,20 @@ extern "C" int qle_enable_gating(qle_batch* h, int32_t on)
 {
     QLE_TRY(check_handle(h));
     if (on && !h->last_corr) {
-        HIP_TRY(hipMalloc((void**)&h->last_corr, sizeof(int32_t) * (size_t)h->Bp));
-        HIP_TRY(hipMalloc((void**)&h->flags, (size_t)h->Bp));
-        HIP_TRY(hipMemsetAsync(h->last_corr, 0xFF, sizeof(int32_t) * (size_t)h->Bp, h->stream));  // -1
-        HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));
+        int32_t* lc = nullptr;
+        uint8_t* fl = nullptr;
+        hipError_t e = hipMalloc((void**)&lc, sizeof(int32_t) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc((void**)&fl, (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMemsetAsync(fl, 0, (size_t)h->Bp, h->stream);
+        if (e != hipSuccess) {
+            if (lc) (void)hipFree(lc);
+            if (fl) (void)hipFree(fl);
+            return fail(QLE_ERR_NOMEM, "gating arrays: %s", hipGetErrorString(e));
+        }
+        h->last_corr = lc; h->flags = fl;
+        // upds_since_correction = 0 before the next tick (EKF.cpp:77): as if tick-1 had corrected
+        hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->last_corr, (int32_t)(h->tick - 1), h->B);
+        HIP_TRY(hipGetLastError());
     }
     h->gating = on != 0;
     return QLE_OK;
@@ -831,7 +588,6 @@ extern "C" int qle_filter_update(qle_batch* h, const double* u, const double* z,
 {
     QLE_TRY(check_handle(h));
     if (!h->gating) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
-    if (z == nullptr && h->flags) HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));  // performed_correction = false
     h->have_stamps = false;
     return qle_step(h, u, z, measurement_ready);
 }
@@ -841,7 +597,6 @@ extern "C" int qle_filter_update_stamped(qle_batch* h, const double* u, const do
 {
     QLE_TRY(check_handle(h));
     if (!h->gating) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
-    if (z == nullptr && h->flags) HIP_TRY(hipMemsetAsync(h->flags, 0, (size_t)h->Bp, h->stream));
     h->t_curr = t_curr;
     h->have_stamps = false;
     if (h->mr && apriltag_time && z) {
@@ -872,20 +627,42 @@ extern "C" int qle_set_uniform_measurement_age(qle_batch* h, double seconds)
     return QLE_OK;
 }
 
+template <typename T>
+static int upds_since_t(qle_batch* h, int32_t* d_out)
+{
+    hipLaunchKernelGGL((k_upds_since<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)state_cur(h), (const int32_t*)h->last_corr, (int32_t)h->tick, d_out, h->B);
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
 extern "C" int qle_get_tick_flags(qle_batch* h, uint8_t* performed_correction, uint8_t* consumed, int32_t* upds_since_correction)
 {
     QLE_TRY(check_handle(h));
     if (!h->last_corr) return fail(QLE_ERR_STATE, "gating is not enabled (qle_enable_gating)");
     QLE_GUARD_BEGIN
     std::vector<uint8_t> f((size_t)h->B);
-    std::vector<int32_t> lc((size_t)h->B);
     HIP_TRY(hipMemcpyAsync(f.data(), h->flags, (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
-    HIP_TRY(hipMemcpyAsync(lc.data(), h->last_corr, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+    if (upds_since_correction) {   // EKF.cpp:292-299; staged in chunks of the AoS staging buffer
+        int32_t* d_out = reinterpret_cast<int32_t*>(h->stage);
+        if ((size_t)h->B * sizeof(int32_t) <= (size_t)kStageDoubles * sizeof(double)) {
+            QLE_TRY(BY_DTYPE(h, upds_since_t, h, d_out));
+            HIP_TRY(hipMemcpyAsync(upds_since_correction, d_out, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream));
+        } else {
+            int32_t* tmp = nullptr;
+            HIP_TRY(hipMalloc((void**)&tmp, sizeof(int32_t) * (size_t)h->B));
+            int rc = BY_DTYPE(h, upds_since_t, h, tmp);
+            hipError_t e = rc == QLE_OK ? hipMemcpyAsync(upds_since_correction, tmp, sizeof(int32_t) * (size_t)h->B, hipMemcpyDeviceToHost, h->stream) : hipSuccess;
+            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+            (void)hipFree(tmp);
+            if (rc != QLE_OK) return rc;
+            if (e != hipSuccess) return fail(QLE_ERR_HIP, "tick flags: %s", hipGetErrorString(e));
+        }
+    }
     HIP_TRY(hipStreamSynchronize(h->stream));
+    // the flag bytes are written by ticks that carry tag poses; after a predict-only tick nothing was performed or consumed
+    const bool fresh = h->flags_tick == h->tick - 1;
     for (int64_t i = 0; i < h->B; ++i) {
-        if (performed_correction) performed_correction[i] = f[(size_t)i] & 1;
-        if (consumed) consumed[i] = (f[(size_t)i] >> 1) & 1;
-        if (upds_since_correction) upds_since_correction[i] = (int32_t)(h->tick - 1 - lc[(size_t)i]);  // EKF.cpp:292-299
+        if (performed_correction) performed_correction[i] = fresh ? (f[(size_t)i] & 1) : 0;
+        if (consumed) consumed[i] = fresh ? ((f[(size_t)i] >> 1) & 1) : 0;
     }
     return QLE_OK;
     QLE_GUARD_END
@@ -895,20 +672,39 @@ template <typename T>
 static int seed_t(qle_batch* h, int reinit)
 {
     const qle_derived& d = h->der;
+    QLE_TRY(mr_prepare(h));   // a pending whole-batch history restart first; the seeded filters then restart theirs
     hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)state_cur(h),
-                       (T)d.cov_init[0], (T)d.cov_init[3], (T)d.cov_init[6], (T)d.cov_init[9], (T)d.cov_init[12], reinit, h->B);
+                       (T)d.cov_init[0], (T)d.cov_init[3], (T)d.cov_init[6], (T)d.cov_init[9], (T)d.cov_init[12], reinit, (int32_t)h->tick,
+                       h->last_corr, h->mr ? h->hist_first : (int32_t*)nullptr, h->mr ? h->fresh_from : (int32_t*)nullptr, h->B);
     HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+extern "C" int qle_initialize_state_masked(qle_batch* h, const double* z, const uint8_t* mask, int32_t reinit_bias)
+{
+    QLE_TRY(check_handle(h));
+    if (!z) return fail(QLE_ERR_INVALID, "z is null");
+    QLE_TRY(BY_DTYPE(h, pack_z, h, z, mask, h->tick_z));
+    QLE_TRY(BY_DTYPE(h, seed_t, h, reinit_bias));
+    h->state_set = true;
     return QLE_OK;
 }
 extern "C" int qle_initialize_state(qle_batch* h, const double* z, int32_t reinit_bias)
 {
+    return qle_initialize_state_masked(h, z, nullptr, reinit_bias);
+}
+extern "C" int qle_get_state_initialized(qle_batch* h, uint8_t* state_initialized)
+{
     QLE_TRY(check_handle(h));
-    if (!z) return fail(QLE_ERR_INVALID, "z is null");
-    QLE_TRY(BY_DTYPE(h, pack_z, h, z, (const uint8_t*)nullptr, h->tick_z));
-    QLE_TRY(BY_DTYPE(h, seed_t, h, reinit_bias));
-    h->state_set = true;
-    h->hist_dirty = true;
+    if (!state_initialized) return fail(QLE_ERR_INVALID, "output is null");
+    QLE_GUARD_BEGIN
+    std::vector<double> x((size_t)h->B * kXW);
+    QLE_TRY(BY_DTYPE(h, unpack_rows, h, state_cur(h), kXW, kXW, x.data(), kSW, 0));
+    for (int64_t i = 0; i < h->B; ++i) {
+        const double* q = &x[(size_t)i * kXW + 6];
+        state_initialized[i] = (q[0] != 0.0 || q[1] != 0.0 || q[2] != 0.0 || q[3] != 0.0) ? 1 : 0;
+    }
     return QLE_OK;
+    QLE_GUARD_END
 }
 
 // ---------------------------------------------------------------- reporting
@@ -1079,23 +875,7 @@ extern "C" int qle_run(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n
     return QLE_OK;
 }
 
-// On-chip-resident variant: ONE launch advances every filter by n ticks with x and P held in
-// registers; HBM traffic is the state once plus the inputs.  Not the unit of work of the headline
-// metric (one launch per tick); reported separately.
-template <typename T>
-static int run_resident_t(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
-{
-    const DevParams<T>& p = dev<T>(h);
-    const dim3 g = grid_for(h, h->block), b(h->block);
-    const T* pfp = (const T*)h->pfp;
-    const int64_t pu = (int64_t)(in->pitch_u / h->wsz), pz = (int64_t)(in->pitch_z / h->wsz);
-#define QLE_RES(D, F) hipLaunchKernelGGL((k_run_resident<T, D, F>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
-    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_RES(true, true); else QLE_RES(true, false); }
-    else { if (h->pfp_on) QLE_RES(false, true); else QLE_RES(false, false); }
-#undef QLE_RES
-    HIP_TRY(hipGetLastError());
-    return QLE_OK;
-}
+
 extern "C" int qle_run_resident(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
 {
     QLE_TRY(check_handle(h));
@@ -1171,7 +951,17 @@ extern "C" int qle_synth_generate(qle_batch* h, qle_inputs* in, const qle_synth_
     // seed every filter from the generator's first (pre-sequence) tag pose, left in tick_z
     QLE_TRY(BY_DTYPE(h, seed_t, h, 1));
     h->state_set = true;
-    h->hist_dirty = true;
+    return QLE_OK;
+}
+
+extern "C" int qle_synth_get_truth(qle_batch* h, const qle_inputs* in, double* pose, double* imu_bias)
+{
+    QLE_TRY(check_handle(h));
+    if (!in || in->h != h) return fail(QLE_ERR_INVALID, "inputs do not belong to this handle");
+    if (!in->has_truth) return fail(QLE_ERR_STATE, "inputs hold no generated truth (qle_synth_generate)");
+    HIP_TRY(hipStreamSynchronize(h->stream));
+    if (pose) HIP_TRY(hipMemcpy(pose, in->truth, (size_t)h->B * 7 * sizeof(double), hipMemcpyDeviceToHost));
+    if (imu_bias) HIP_TRY(hipMemcpy(imu_bias, in->truth_bias, (size_t)h->B * 6 * sizeof(double), hipMemcpyDeviceToHost));
     return QLE_OK;
 }
 

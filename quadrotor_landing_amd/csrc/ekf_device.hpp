@@ -34,10 +34,49 @@ __device__ __forceinline__ double t_atan2(double a, double b) { return atan2(a, 
 __device__ __forceinline__ void t_sincos(float v, float* s, float* c) { sincosf(v, s, c); }
 __device__ __forceinline__ void t_sincos(double v, double* s, double* c) { sincos(v, s, c); }
 
-// Packed upper-triangular index of the symmetric 15x15 covariance, row-major.
+// Packed storage order of the symmetric 15x15 covariance (120 words).
+//
+// P is 5x5 blocks of 3x3 (r, v, th, ab, wb).  The order serves two kernel families at once:
+//   * one lane per filter (k_predict / k_step): the words of block-row r come first, then v, th, ab, wb, so
+//     that the levelled predict can store a block-row as soon as it is final (qle::level_first_word);
+//   * four lanes per filter (ekf_quad.hpp): lane j in {0,1,2} of a quad owns COLUMN j of every 3x3 block
+//     (b, c), b <= c, and loads 40 of the 120 words as ten 16-byte quads: memory quad 3m + l is the m-th
+//     quad of lane l.  Every lane's 40-word list has the same shape: per block-row b the stored part of
+//     the diagonal block (D0 = element (3b+l, 3b+l), D1 = element (3b+(l+2)%3, 3b+l)) followed by the
+//     three words of column l of each block (b, c), c > b.  The symmetric duplicate a lane does not store,
+//     element (3b+(l+1)%3, 3b+l), is lane (l+1)%3's D1.
+// Element (i, k), i <= k, block (b, c) = (i/3, k/3), position (ii, kk) = (i%3, k%3):
+//   b <  c : lane kk, list position base(b) + 2 + 3 (c-b-1) + ii
+//   b == c : ii == kk -> lane kk, position base(b);  (0,1) -> lane 1, (1,2) -> lane 2, (0,2) -> lane 0, position base(b)+1
+// with base = {0, 14, 25, 33, 38}; word = 4 (3 (pos/4) + lane) + pos%4.
+__host__ __device__ constexpr int quad_group_base(int b) { return b == 0 ? 0 : b == 1 ? 14 : b == 2 ? 25 : b == 3 ? 33 : 38; }
+__host__ __device__ constexpr int quad_word(int lane, int pos) { return 4 * (3 * (pos / 4) + lane) + pos % 4; }
 __host__ __device__ constexpr int sidx(int i, int j)
 {
-    return (i <= j) ? (i * 15 - (i * (i - 1)) / 2 + (j - i)) : (j * 15 - (j * (j - 1)) / 2 + (i - j));
+    const int lo = i <= j ? i : j, hi = i <= j ? j : i;
+    const int b = lo / 3, c = hi / 3, ii = lo % 3, kk = hi % 3;
+    if (b == c) {
+        if (ii == kk) return quad_word(kk, quad_group_base(b));
+        return quad_word((ii == 0 && kk == 1) ? 1 : (ii == 1 && kk == 2) ? 2 : 0, quad_group_base(b) + 1);
+    }
+    return quad_word(kk, quad_group_base(b) + 2 + 3 * (c - b - 1) + ii);
+}
+// Block-row (0 = r ... 4 = wb) of the element stored in word w.
+__host__ __device__ constexpr int word_block_row(int w)
+{
+    const int pos = 4 * ((w / 4) / 3) + w % 4;
+    return pos < 14 ? 0 : pos < 25 ? 1 : pos < 33 ? 2 : pos < 38 ? 3 : 4;
+}
+// First word (a multiple of vw) from which on every stored element belongs to block-row >= b: the quads from
+// there to the end are final once the levelled predict has finished block-row b.
+__host__ __device__ constexpr int level_first_word(int b, int vw)
+{
+    int w0 = 120;
+    for (int w = 119; w >= 0; --w) {
+        if (word_block_row(w) < b) break;
+        if (w % vw == 0) w0 = w;
+    }
+    return w0;
 }
 #define QLE_PS(i, j) P[::qle::sidx((i), (j))]
 
@@ -509,13 +548,26 @@ __device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const 
 }
 
 // ------------------------------------------------------------------- update
-// correction_step, EKF.cpp:417-502.  z = [r_c_tc(3), q_ct(x,y,z,w)(4)].
-// obs receives r_t_vt_obs(3), q_tv_obs(4) (members written at EKF.cpp:431-443).
-// emit_obs(obs) is called as soon as the reported observation exists, before the six fusions, so that a
-// caller that only stores it does not keep seven more values alive through the register-critical part.
+// correction_step, EKF.cpp:417-502, in two parts.  z = [r_c_tc(3), q_ct(x,y,z,w)(4)].
+//
+// ekf_update_prepare: everything that does not need the covariance -- the innovation (EKF.cpp:429-450), G (EKF.cpp:453-459),
+//   R_k = N R N^T (EKF.cpp:462-472) and its L D L^T factor, the decorrelated measurement y' = L^-1 dy, G' = L^-1 G.  It is a long
+//   DEPENDENT chain of scalar instructions (a lone wave pays ~9 cycles for each, profiles/r02_tuning.md), so the tick kernels run it
+//   right after the predict's own scalar part, while the covariance loads are still in flight, instead of after the predict.
+// ekf_update_apply: the six scalar fusions on the live covariance (EKF.cpp:475-481 in sequential form) and the injection
+//   (EKF.cpp:486-501).
+// obs receives r_t_vt_obs(3), q_tv_obs(4) (members written at EKF.cpp:431-443) through emit_obs(obs), called as soon as the reported
+// observation exists so that a caller that only stores it does not keep seven more values alive.
+template <typename T>
+struct UpdatePrep {
+    T dy[6];      // decorrelated innovation y'
+    T d[6];       // diagonal of R' = D
+    T Gm[6][6];   // G' = L^-1 G over the state columns J = {r0,r1,r2,th0,th1,th2}
+};
+
 template <typename T, bool DIRECT, typename EmitObs>
-__device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
-                                                const T (&z)[7], EmitObs&& emit_obs)
+__device__ __forceinline__ void ekf_update_prepare(const DevParams<T>& p, const Noise<T>& nz, const T (&x)[16], const T (&z)[7],
+                                                   UpdatePrep<T>& u, EmitObs&& emit_obs)
 {
     T obs[7];
     T q[4] = {x[6], x[7], x[8], x[9]};
@@ -529,7 +581,7 @@ __device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noi
         qo[0] = -t[0]; qo[1] = -t[1]; qo[2] = -t[2]; qo[3] = t[3];
         quat_norm(qo);                                       // EKF.cpp:432
     }
-    T dy[6];
+    T (&dy)[6] = u.dy;
     {
         // EKF.cpp:434-444: -(q * T_vc * r_c_tc) with q = q_tv_obs (direct) or q_check
         T Cq[9];
@@ -559,8 +611,7 @@ __device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noi
 
     // G restricted to the six state columns it touches, J = {r0,r1,r2,th0,th1,th2} = {0,1,2,6,7,8}:
     //   G = [I Gx; 0 I] over J, Gx = Cc [Cc^T r]x unless direct (EKF.cpp:453-459).
-    constexpr int J[6] = {0, 1, 2, 6, 7, 8};
-    T Gm[6][6];
+    T (&Gm)[6][6] = u.Gm;
 #pragma unroll
     for (int a = 0; a < 6; ++a) {
 #pragma unroll
@@ -611,11 +662,10 @@ __device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noi
     // R' = D is diagonal, so the six components can be fused one scalar at a time and
     // h = P g'^T is read from the live covariance (no 15x6 copy of P G^T is kept).
     // In the direct method G' stays unit lower triangular: only entries m <= c are touched.
-    T d[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
-        d[c] = Rk[c][c];
-        const T invd = T(1) / d[c];
+        u.d[c] = Rk[c][c];
+        const T invd = T(1) / u.d[c];
 #pragma unroll
         for (int j = c + 1; j < 6; ++j) {
             const T l = Rk[c][j] * invd;
@@ -627,6 +677,13 @@ __device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noi
             dy[j] -= l * dy[c];
         }
     }
+}
+
+template <typename T, bool DIRECT>
+__device__ __forceinline__ void ekf_update_apply(const DevParams<T>& p, T (&x)[16], T (&P)[120], const UpdatePrep<T>& u)
+{
+    constexpr int J[6] = {0, 1, 2, 6, 7, 8};
+    const T (&Gm)[6][6] = u.Gm;
     // Six scalar updates (EKF.cpp:475-481 in sequential form): for component c
     //   h = P g'_c^T, s = g'_c h + d_c, k = h/s, dx += k (y'_c - g'_c dx), P -= k h^T.
     T dx[15];
@@ -643,36 +700,59 @@ __device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noi
                 if (!DIRECT || m <= c) acc += Gm[c][m] * QLE_PS(k, J[m]);
             h[k] = acc;
         }
-        T s = d[c], nu = dy[c];
+        T s = u.d[c], nu = u.dy[c];
 #pragma unroll
         for (int m = 0; m < 6; ++m)
             if (!DIRECT || m <= c) { s += Gm[c][m] * h[J[m]]; nu -= Gm[c][m] * dx[J[m]]; }
-        // gain k = h / s is never stored: dx += h (nu/s), P(i,k) -= (h_i/s) h_k
+        // gain k = h / s is never stored: dx += h (nu/s), P(i,k) -= (h_i/s) h_k.  In fp32 the sign goes into the scaled h_i once, so
+        // that the 120 updates are plain accumulations (v_fmac_f32, 4 bytes) and not v_fma_f32 with a negated operand (8 bytes): a
+        // lone wave on long straight-line code is bound by instruction supply (profiles/r02_tuning.md; k_step 15.4 -> 14.7 us with the
+        // fast fp32 division).  fp64 keeps the subtraction: there the other form costs registers (38 -> 41.6 us at 65 536 filters).
         const T inv = T(1) / s;
         const T c_nu = inv * nu;
 #pragma unroll
         for (int k = 0; k < 15; ++k) dx[k] += h[k] * c_nu;
+        if (sizeof(T) == 4) {
+            const T ninv = -inv;
 #pragma unroll
-        for (int i = 0; i < 15; ++i) {
-            const T hi = h[i] * inv;
+            for (int i = 0; i < 15; ++i) {
+                const T nhi = h[i] * ninv;
 #pragma unroll
-            for (int k = i; k < 15; ++k) QLE_PS(i, k) -= hi * h[k];
+                for (int k = i; k < 15; ++k) QLE_PS(i, k) += nhi * h[k];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 15; ++i) {
+                const T hi = h[i] * inv;
+#pragma unroll
+                for (int k = i; k < 15; ++k) QLE_PS(i, k) -= hi * h[k];
+            }
         }
     }
 
     // inject, EKF.cpp:486-501
+    T q[4] = {x[6], x[7], x[8], x[9]};
     T dth[3] = {dx[6], dx[7], dx[8]}, qe[4], qn[4];
     quat_exp(dth, qe);
     quat_mul(q, qe, qn);
     quat_norm(qn);
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        x[i] = r[i] + dx[i];
+        x[i] += dx[i];
         x[3 + i] += dx[3 + i];
         x[10 + i] = p.bias_on * (x[10 + i] + dx[9 + i]);
         x[13 + i] = p.bias_on * (x[13 + i] + dx[12 + i]);
     }
     x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+}
+
+template <typename T, bool DIRECT, typename EmitObs>
+__device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
+                                                const T (&z)[7], EmitObs&& emit_obs)
+{
+    UpdatePrep<T> u;
+    ekf_update_prepare<T, DIRECT>(p, nz, x, z, u, emit_obs);
+    ekf_update_apply<T, DIRECT>(p, x, P, u);
 }
 
 template <typename T, bool DIRECT>

@@ -210,6 +210,16 @@ __device__ __forceinline__ void store_P_quads_desc(T* __restrict__ st, int64_t i
     for (int k = Q1 - 1; k >= Q0; --k) st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + ((kXW / VW + k) * kTile + lane) * VW), pack_quad(&P[k * VW]));
 }
 
+// A filter is "not initialised" (state_initialized == false, EKF.cpp:73,129-130) while its stored quaternion is all
+// zero -- the state memory starts zeroed, initialize_state / set_state write a unit quaternion -- and every tick kernel
+// leaves such a filter untouched: no predict, no counters, no history entry, exactly the reference's early return.
+// The flag lives in the record the tick reads anyway, so it costs no traffic.
+template <typename T>
+__device__ __forceinline__ bool filter_uninitialised(const T (&x)[kXW])
+{
+    return x[6] == T(0) && x[7] == T(0) && x[8] == T(0) && x[9] == T(0);
+}
+
 // --------------------------------------------------------- measurement gate
 // Decision logic of filter_update, EKF.cpp:147-186, per filter on the device:
 //   consume  = measurement_ready && (!limit_measurement_freq || upds_since_correction + 1 >= upd_per_meas)
@@ -255,7 +265,7 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 
 // ------------------------------------------------------------- hot kernels
 // Predict tick: reads x16 + P120 + u6, writes x16 + P120 (278 words/filter).
-// Row-major packed P: rows r = words 0..41, v = 42..74, th = 75..98, ab = 99..113, wb = 114..119.
+// Packed P (sidx in ekf_device.hpp): the words of block-row r come first, then v, th, ab, wb.
 // Loads are issued bottom-up and each block-row of the new P is stored as soon as it is final
 // (ekf_predict_levels), so the stores overlap the loads of the rows above inside the one wave a
 // SIMD holds at B = 65 536.  QLE_PREDICT_LEVELS=0 selects the in-place variant (ekf_predict).
@@ -278,10 +288,10 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     constexpr int VW = Quad<T>::VW;
     constexpr int NQ = kPW / VW;
     load_P_quads_desc<T, 0, NQ, NT>(src, i, P);
+    if (filter_uninitialised(x)) return;
     T Pn[kPW];
-    // first word of each block-row in the row-major triangle; a quad is final once every word in it is
-    constexpr int w_th = 75, w_v = 42, w_ab = 99;
-    constexpr int q_ab = (w_ab + VW - 1) / VW, q_th = (w_th + VW - 1) / VW, q_v = (w_v + VW - 1) / VW;
+    // a quad is final once every word in it is: first quad that holds only block-rows >= ab / th / v (ekf_device.hpp)
+    constexpr int q_ab = level_first_word(3, VW) / VW, q_th = level_first_word(2, VW) / VW, q_v = level_first_word(1, VW) / VW;
     ekf_predict_levels<T>(p, nz, x, P, u, accel, Pn, [&](int level) {
         if (level == -1) store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
         else if (level == 0) store_P_quads_desc<T, q_ab, NQ, NT>(dst, i, Pn);
@@ -291,6 +301,7 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     });
 #else
     load_rec<T, kSW, kXW, kPW, NT>(src, i, P);
+    if (filter_uninitialised(x)) return;
     ekf_predict<T>(p, nz, x, P, u, accel);
     store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
     store_rec<T, kSW, kXW, kPW, NT>(dst, i, P);
@@ -342,6 +353,7 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     load_rec<T, kZW, 0, kZW, NT>(zs, i, zr);
     load_rec<T, kSW, 0, kXW, NT>(st, i, x);
     load_P_quads_desc<T, 0, kPW / Quad<T>::VW, NT>(st, i, Po);
+    if (filter_uninitialised(x)) return;
     bool corr = zr[7] != T(0);
     if (GATE) {  // the mask word means "measurement_ready"; decide here (EKF.cpp:147-186)
         const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
@@ -362,6 +374,10 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
     }
     if (corr) {
+        // Measured (profiles/r02_tuning.md): running ekf_update_prepare before the predict's covariance work -- while the loads are
+        // in flight -- does not shorten the tick at 65 536 filters (15.4 us either way: the lone wave is bound by instruction supply
+        // on 29 KiB of straight-line code, not by the load wait) and costs the second wave per SIMD at larger batches (59 vs 51 us
+        // at 262 144 filters), so the correction runs after the predict.
         T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
         ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&obs)[7]) {
             if (aux_accel) {
@@ -443,6 +459,8 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     load_noise<T, PFP>(p, pfp, i, nz);
     T zr[kZW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
+    load_rec<T, kSW, 0, kXW>(ring_slot(ring, m, m.tick - 1), i, x);   // newest entry: is the filter initialised at all?
+    if (filter_uninitialised(x)) return;
     bool corr = zr[7] != T(0);
     if (m.gate) {  // EKF.cpp:147-186
         const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
@@ -521,7 +539,8 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     }
 }
 
-__global__ void k_fill_i32(int32_t* __restrict__ dst, int32_t v, int64_t B)
+template <typename I>   // a template only so that every translation unit may include this header
+__global__ void k_fill_i32(I* __restrict__ dst, I v, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < B) dst[i] = v;
@@ -541,6 +560,7 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
     T x[kXW], P[kPW], u[kUW], un[kUW], accel[3];
     load_rec<T, kSW, 0, kXW>(st, i, x);
     load_rec<T, kSW, kXW, kPW>(st, i, P);
+    if (filter_uninitialised(x)) return;
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
     int64_t t = t0 % T_seq;
@@ -566,7 +586,8 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
 
 // Shift the tick origin: subtract `shift` from every filter's last-correction index so that the
 // 32-bit tick arithmetic never wraps in a long-running service.  "Never / long ago" saturates.
-__global__ void k_rebase_ticks(int32_t* __restrict__ last_corr, int32_t shift, int64_t B)
+template <typename I>
+__global__ void k_rebase_ticks(I* __restrict__ last_corr, I shift, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
@@ -574,6 +595,18 @@ __global__ void k_rebase_ticks(int32_t* __restrict__ last_corr, int32_t shift, i
     // rate limit or ring capacity, which is all the consumers of these indices distinguish
     const int64_t v = (int64_t)last_corr[i] - shift;
     last_corr[i] = (int32_t)(v < -(int64_t)(1 << 30) ? -(int64_t)(1 << 30) : v);
+}
+
+// upds_since_correction (EKF.hpp:128) per filter from the implicit counter: ticks since the filter's last correction,
+// 0 for a filter that is not initialised yet (the reference never advances it, EKF.cpp:129-130).
+template <typename T>
+__global__ void k_upds_since(const T* __restrict__ st, const int32_t* __restrict__ last_corr, int32_t tick, int32_t* __restrict__ out, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    bool init = false;
+    for (int w = 6; w < 10; ++w) init |= st[word_off<T>(w, i, kSW)] != T(0);
+    out[i] = init ? tick - 1 - last_corr[i] : 0;
 }
 
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
@@ -589,6 +622,7 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
     T x[kXW], P[kPW];
     load_rec<T, kSW, 0, kXW>(st, i, x);
     load_rec<T, kSW, kXW, kPW>(st, i, P);
+    if (filter_uninitialised(x)) return;
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
     T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
@@ -661,16 +695,22 @@ __global__ void k_unpack_P_off(const T* __restrict__ st, int n, double* __restri
         for (int b = 0; b < n; ++b) Pi[a * n + b] = (double)st[word_off<T>(kXW + sidx(a, b), i0 + li, kSW)];
 }
 
-// initialize_state, EKF.cpp:305-344, one filter per lane.
+// initialize_state, EKF.cpp:305-344, one filter per lane, for the filters whose tag record's mask word is set
+// (the node seeds a filter on ITS first detection, NODE.cpp:169-174).  A filter that was not initialised before starts
+// its counters here: upds_since_correction = 0 (EKF.cpp:77), i.e. last_corr = tick - 1.  Every seeded filter restarts
+// its multirate history with the single entry "state now" (EKF.cpp:337-339).
 template <typename T>
 __global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__ st, T cov0, T cov1, T cov2, T cov3, T cov4,
-                       int reinit_bias, int64_t B)
+                       int reinit_bias, int32_t tick, int32_t* __restrict__ last_corr, int32_t* __restrict__ hist_first,
+                       int32_t* __restrict__ fresh_from, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     T zr[kZW], x[kXW], P[kPW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
+    if (zr[7] == T(0)) return;
     load_rec<T, kSW, 0, kXW>(st, i, x);
+    const bool fresh = filter_uninitialised(x);
     T qct[4] = {zr[3], zr[4], zr[5], zr[6]}, t[4], qn[4], C[9], pv[3];
     quat_mul(p.q_vc, qct, t);                       // EKF.cpp:310
     qn[0] = -t[0]; qn[1] = -t[1]; qn[2] = -t[2]; qn[3] = t[3];
@@ -695,6 +735,8 @@ __global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__
     }
     store_rec<T, kSW, 0, kXW>(st, i, x);
     store_rec<T, kSW, kXW, kPW>(st, i, P);
+    if (fresh && last_corr) last_corr[i] = tick - 1;
+    if (hist_first) { hist_first[i] = tick - 1; fresh_from[i] = tick - 1; }
 }
 
 // What the node publishes after a tick (NODE.cpp:192-220), AoS fp64, one chunk.

@@ -1,0 +1,66 @@
+// tu_misc.hip -- launchers of k_step_mr, k_update, k_run_resident
+// Compiled once per compute dtype (-DQLE_TU_T=float|double); see ekf_host.hpp.
+#include "ekf_host.hpp"
+#ifndef QLE_TU_T
+#error "compile with -DQLE_TU_T=float or -DQLE_TU_T=double"
+#endif
+
+// One multirate tick that carries tag poses (predict-only multirate ticks go through launch_predict).
+template <typename T>
+int launch_step_mr(qle_batch* h, const void* u, const void* z)
+{
+    QLE_TRY(mr_prepare(h));
+    const DevParams<T>& p = dev<T>(h);
+    const GateParams gp = make_gate(h);
+    const MrParams m = make_mr(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
+    const T* pfp = (const T*)h->pfp;
+    const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
+#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, (T*)h->ring, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->fresh_from, h->last_corr, h->flags, h->delay_cur, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
+    else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
+#undef QLE_MR_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+
+
+template <typename T, bool DIRECT>
+static int launch_update_d(qle_batch* h, const void* z)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T *st = (T*)state_cur(h), *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
+    const T* pfp = (const T*)h->pfp;
+    if (h->pfp_on) hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
+    else hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+template <typename T>
+int launch_update(qle_batch* h, const void* z)
+{
+    return h->pub.direct_orien_method ? launch_update_d<T, true>(h, z) : launch_update_d<T, false>(h, z);
+}
+
+// On-chip-resident variant: ONE launch advances every filter by n ticks with x and P held in
+// registers; HBM traffic is the state once plus the inputs.  Not the unit of work of the headline
+// metric (one launch per tick); reported separately.
+template <typename T>
+int run_resident_t(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    const T* pfp = (const T*)h->pfp;
+    const int64_t pu = (int64_t)(in->pitch_u / h->wsz), pz = (int64_t)(in->pitch_z / h->wsz);
+#define QLE_RES(D, F) hipLaunchKernelGGL((k_run_resident<T, D, F>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_RES(true, true); else QLE_RES(true, false); }
+    else { if (h->pfp_on) QLE_RES(false, true); else QLE_RES(false, false); }
+#undef QLE_RES
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+template int launch_step_mr<QLE_TU_T>(qle_batch*, const void*, const void*);
+template int launch_update<QLE_TU_T>(qle_batch*, const void*);
+template int run_resident_t<QLE_TU_T>(qle_batch*, const qle_inputs*, int64_t, int64_t);

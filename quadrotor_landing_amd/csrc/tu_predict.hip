@@ -1,0 +1,32 @@
+// tu_predict.hip -- launcher of k_predict (one lane per filter, predict-only tick)
+// Compiled once per compute dtype (-DQLE_TU_T=float|double); see ekf_host.hpp.
+#include "ekf_host.hpp"
+
+#ifndef QLE_TU_T
+#error "compile with -DQLE_TU_T=float or -DQLE_TU_T=double"
+#endif
+
+
+// prediction_step from `src` into `dst`; keep_u: the record also stores the IMU sample (multirate history).
+template <typename T>
+int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u)
+{
+    const DevParams<T>& p = dev<T>(h);
+    const dim3 g = grid_for(h, h->block), b(h->block);
+    T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
+    const T* pfp = (const T*)h->pfp;
+#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B, h->split)
+#define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
+    const int nt = effective_nt(h);
+#define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)
+    if (keep_u) QLE_PRED_M(true);
+    else if (nt == 3) QLE_PRED_N(3, false);
+    else QLE_PRED_M(false);
+#undef QLE_PRED_M
+#undef QLE_PRED_N
+#undef QLE_PRED
+    HIP_TRY(hipGetLastError());
+    return QLE_OK;
+}
+
+template int launch_predict_sd<QLE_TU_T>(qle_batch*, const void*, const void*, void*, bool);

@@ -129,6 +129,12 @@ class BatchedRelativePoseEKF:
         """Per-filter [Q diag 12, ab_static 3, wb_static 3, R diag 6]; None = shared parameters."""
         check(lib().qle_set_filter_params(self._h, None if pfp is None else _dp(_f64(pfp, (self.batch, 24)))))
 
+    def get_filter_params(self):
+        """The per-filter [Q diag 12, ab_static 3, wb_static 3, R diag 6] records as the device holds them."""
+        out = np.empty((self.batch, 24))
+        check(lib().qle_get_filter_params(self._h, _dp(out)))
+        return out
+
     # ---- state
     def set_state(self, x, P):
         n = self.num_states
@@ -140,9 +146,18 @@ class BatchedRelativePoseEKF:
         check(lib().qle_get_state(self._h, _dp(x), _dp(P)))
         return x, P
 
-    def initialize_state(self, z, reinit_bias=False):
-        """RelativePoseEKF::initialize_state (relative_pose_EKF.cpp:305-344) from each filter's first tag pose."""
-        check(lib().qle_initialize_state(self._h, _dp(_f64(z, (self.batch, 7))), int(bool(reinit_bias))))
+    def initialize_state(self, z, reinit_bias=False, mask=None):
+        """RelativePoseEKF::initialize_state (relative_pose_EKF.cpp:305-344) from each filter's first tag pose.
+        mask [batch]: seed only those filters (the node seeds a filter on its own first detection,
+        relative_pose_EKF_node.cpp:169-174); filters never seeded are skipped by every tick (relative_pose_EKF.cpp:129-130)."""
+        m = _u8(mask, (self.batch,))
+        check(lib().qle_initialize_state_masked(self._h, _dp(_f64(z, (self.batch, 7))), None if m is None else m.ctypes.data_as(_pu8),
+                                                int(bool(reinit_bias))))
+
+    def state_initialized(self):
+        out = np.zeros(self.batch, np.uint8)
+        check(lib().qle_get_state_initialized(self._h, out.ctypes.data_as(_pu8)))
+        return out
 
     def enable_aux(self, on=True):
         check(lib().qle_enable_aux(self._h, int(bool(on))))
@@ -231,6 +246,12 @@ class BatchedRelativePoseEKF:
         for k, v in kw.items():
             setattr(c, k, v)
         check(lib().qle_synth_generate(self._h, inputs._h, C.byref(c)))
+
+    def synth_truth(self, inputs):
+        """(pose [batch,7], imu_bias [batch,6]) of the generator's truth at the end of the sequence."""
+        pose = np.empty((self.batch, 7)); bias = np.empty((self.batch, 6))
+        check(lib().qle_synth_get_truth(self._h, inputs._h, _dp(pose), _dp(bias)))
+        return pose, bias
 
     def synth_rmse(self, inputs):
         out = np.zeros(3)

@@ -24,18 +24,18 @@ from util import (GOLDEN, assert_state_close, golden_kwargs, meas_near, oracle_p
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["default", "rows-forced", "lanes-only"])
+@pytest.fixture(autouse=True, params=["default", "lanes-only", "coop-forced"])
 def kernel_family(request, monkeypatch):
-    """Two kernel families implement the plain single-rate tick: one lane per filter (ekf_kernels.hpp) and
-    rows across lanes (16 lanes per filter, ekf_rows.hpp; by default only for small fp64 batches).  Every test
-    runs with the default policy, with the rows kernel forced wherever it is eligible, and with it disabled,
-    so both families are checked against the oracle in both dtypes (QLE_ROWS_MAX is read at handle creation)."""
+    """Two kernel families implement the single-rate tick: one lane per filter (ekf_kernels.hpp) and the workgroup-cooperative
+    kernel (ekf_quad_kernels.hpp: one scalar wave + the covariance spread over quads of lanes; by default only for small fp64
+    batches).  Every test runs with the default policy, with the cooperative kernel forced for every tick, and with it disabled,
+    so both families are checked against the oracle in both dtypes (QLE_QUAD is read at handle creation)."""
     if request.param == "lanes-only":
-        monkeypatch.setenv("QLE_ROWS_MAX", "0")
-    elif request.param == "rows-forced":
-        monkeypatch.setenv("QLE_ROWS_MAX", str(1 << 40))
+        monkeypatch.setenv("QLE_QUAD", "0")
+    elif request.param == "coop-forced":
+        monkeypatch.setenv("QLE_QUAD", "3")
     else:
-        monkeypatch.delenv("QLE_ROWS_MAX", raising=False)
+        monkeypatch.delenv("QLE_QUAD", raising=False)
     return request.param
 
 F64 = dict(rtol=1e-12, atol=1e-14, qtol=1e-11)

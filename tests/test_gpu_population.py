@@ -1,0 +1,201 @@
+"""GPU tests of the population-level features: BASELINE cfg 5 as specified (fp32, direct method, per-filter
+perturbed parameters drawn on the device, per-device RMSE reduction) checked against the oracle on the very
+population the device generated, and per-filter state_initialized (filters seeded on their own first detection,
+relative_pose_EKF.cpp:129-130, 305-344; relative_pose_EKF_node.cpp:169-174).
+
+Tolerances: fp32 engine vs fp64 oracle -- one step rtol 2e-5 / atol 2e-6 (state), free run <= 5e-3; fp64 1e-10.
+"""
+import numpy as np
+import pytest
+
+import oracle
+import quadrotor_landing_amd as qla
+from util import assert_state_close, meas_near, quat_err, rand_imu, rand_states
+
+pytestmark = pytest.mark.gpu
+
+CFG3 = dict(update_freq=400.0, measurement_freq=30.0, limit_measurement_freq=1, direct_orien_method=1, est_bias=1,
+            Q_a=[0.0005] * 3, Q_w=[0.00005] * 3, Q_ab=[5e-5] * 3, Q_wb=[5e-6] * 3, R_r=[0.015, 0.015, 0.020], R_ang=[0.0015, 0.0015, 0.04])
+
+
+@pytest.fixture(autouse=True, params=["default", "lanes-only", "coop-forced"])
+def kernel_family(request, monkeypatch):
+    """default policy / one lane per filter only / the workgroup-cooperative kernel (ekf_quad_kernels.hpp) for every tick."""
+    monkeypatch.delenv("QLE_QUAD", raising=False)
+    if request.param == "lanes-only":
+        monkeypatch.setenv("QLE_QUAD", "0")
+    elif request.param == "coop-forced":
+        monkeypatch.setenv("QLE_QUAD", "3")
+    return request.param
+
+
+def _host_rmse_sums(x, truth_pose):
+    """out[0] = sum |r - r_true|^2, out[1] = sum |log(q_true^-1 (x) q)|^2, out[2] = count (k_rmse, synth_kernels.hpp)."""
+    er = ((x[:, 0:3] - truth_pose[:, 0:3]) ** 2).sum()
+    qt = truth_pose[:, 3:7] * np.array([-1, -1, -1, 1.0]); q = x[:, 6:10]
+    av, aw, bv, bw = qt[:, :3], qt[:, 3:4], q[:, :3], q[:, 3:4]
+    dq = np.concatenate([aw * bv + bw * av + np.cross(av, bv), aw * bw - np.sum(av * bv, axis=1, keepdims=True)], axis=1)
+    dq[dq[:, 3] < 0] *= -1
+    dq /= np.linalg.norm(dq, axis=1, keepdims=True)
+    m = np.linalg.norm(dq[:, :3], axis=1)
+    k = np.where(m < 1e-10, 2 / dq[:, 3] * (1 - (m / dq[:, 3]) ** 2 / 3), 2 * np.arctan2(m, dq[:, 3]) / np.where(m < 1e-10, 1, m))
+    th = dq[:, :3] * k[:, None]
+    return np.array([er, (th ** 2).sum(), float(x.shape[0])])
+
+
+def test_cfg5_population_as_specified(kernel_family):
+    """BASELINE cfg 5 on one device's shard: 32 768 fp32 filters, direct method, per-filter Q / static biases drawn by the
+    device generator, the cfg 3 schedule (400 Hz predict, fused update every 14th tick).  The drawn parameters, the
+    inputs and the truth are read back; a strided 256-filter slice is re-run by the oracle with exactly those
+    per-filter parameters; the per-device RMSE reduction is recomputed on the host."""
+    B, T = 32768, 56
+    thm = np.zeros(T, np.uint8); thm[13::14] = 1
+    ekf = qla.BatchedRelativePoseEKF(B, "f32", **CFG3)
+    seq = ekf.make_inputs(T, thm)
+    ekf.synth_generate(seq, seed=0xE4F00005, filter_offset=3 * B, perturb_filter_params=True)
+    pfp = ekf.get_filter_params()
+    x0, P0 = ekf.get_state()
+    # (i) the drawn population: Q scaled per group by 10^U(-0.5, 0.5), static biases ~ N(0, 0.1), N(0, 0.01), R unchanged
+    po = oracle.make_params(**CFG3)
+    base_Q = np.array(list(po.Q)); base_R = np.array(list(po.R))
+    ratio = pfp[:, :12] / base_Q
+    assert np.all(ratio > 10 ** -0.5 * (1 - 1e-6)) and np.all(ratio < 10 ** 0.5 * (1 + 1e-6))
+    for g in range(4):   # one scale per group of three
+        np.testing.assert_allclose(ratio[:, 3 * g], ratio[:, 3 * g + 1], rtol=1e-6)
+        np.testing.assert_allclose(ratio[:, 3 * g], ratio[:, 3 * g + 2], rtol=1e-6)
+    assert 0.25 < np.log10(ratio[:, 0]).std() < 0.32           # uniform on (-0.5, 0.5): sigma = 0.289
+    assert 0.09 < pfp[:, 12:15].std() < 0.11 and 0.009 < pfp[:, 15:18].std() < 0.011
+    np.testing.assert_allclose(pfp[:, 18:24], np.broadcast_to(base_R, (B, 6)), rtol=1e-6)
+    # (ii) run, full-size properties
+    ekf.run(seq, 0, T)
+    assert ekf.count_nonfinite() == 0
+    xg, Pg = ekf.get_state()
+    np.testing.assert_allclose(np.linalg.norm(xg[:, 6:10], axis=1), 1.0, atol=1e-5)
+    assert np.all(np.einsum("bii->bi", Pg) > 0)
+    np.testing.assert_allclose(Pg, Pg.transpose(0, 2, 1), atol=0)
+    # (iii) a strided slice against the oracle with the downloaded per-filter parameters
+    idx = np.arange(0, B, 128)
+    U = np.empty((T, idx.size, 6)); Z = np.zeros((T, idx.size, 7)); M = np.zeros((T, idx.size), np.uint8)
+    for t in range(T):
+        u, z, m = seq.download_tick(t)
+        U[t], Z[t], M[t] = u[idx], z[idx], m[idx]
+    xr, Pr = oracle.run_batch(po, x0[idx], P0[idx], U, Z, M, per_filter_params=pfp[idx])
+    assert_state_close(xg[idx], Pg[idx], xr, Pr, 5e-3, 5e-3, 5e-3)
+    assert M.sum() == 4 * idx.size
+    # (iv) the per-device RMSE reduction against a host computation on the downloaded state and truth
+    truth_pose, truth_bias = ekf.synth_truth(seq)
+    got = ekf.synth_rmse(seq)
+    want = _host_rmse_sums(xg, truth_pose)
+    np.testing.assert_allclose(got, want, rtol=1e-10)
+    assert np.sqrt(got[0] / got[2]) < 0.5 and np.sqrt(got[1] / got[2]) < 0.5    # the filters track the truth
+    assert truth_bias.shape == (B, 6) and 0.08 < truth_bias[:, :3].std() < 0.12
+    ekf.close()
+
+
+@pytest.mark.parametrize("dtype", ["f32", "f64"])
+def test_direct_method_step_with_per_filter_parameters_vs_oracle(dtype, kernel_family):
+    """One fused tick (predict + correct, direct orientation method) with per-filter Q, static biases and R: the cfg 5
+    kernel instantiation, against the oracle on the same parameters, all filters correcting and a mixed mask."""
+    rng = np.random.default_rng(505)
+    kw = dict(CFG3, ab_static=[0.2, -0.09, -0.03], wb_static=[-0.02, -0.01, 0.0])
+    po = oracle.make_params(**kw)
+    B = 320
+    x, P = rand_states(rng, B, 15, cov_scale=0.3)
+    pfp = np.empty((B, 24))
+    pfp[:, :12] = np.array(list(po.Q)) * 10 ** rng.uniform(-0.5, 0.5, size=(B, 12))
+    pfp[:, 12:15] = rng.normal(size=(B, 3)) * 0.1
+    pfp[:, 15:18] = rng.normal(size=(B, 3)) * 0.01
+    pfp[:, 18:24] = np.array(list(po.R)) * 10 ** rng.uniform(-0.3, 0.3, size=(B, 6))
+    u = rand_imu(rng, B)
+    z = meas_near(rng, po, x, ang=0.2, pos=0.05)
+    rnd = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype == "f32" else (lambda a: a)
+    x, P, pfp, u, z = rnd(x), rnd(P), rnd(pfp), rnd(u), rnd(z)
+    for mask in (np.ones(B, np.uint8), (rng.uniform(size=B) < 0.5).astype(np.uint8)):
+        ekf = qla.BatchedRelativePoseEKF(B, dtype, **kw)
+        ekf.set_filter_params(pfp)
+        np.testing.assert_array_equal(ekf.get_filter_params(), pfp)
+        ekf.set_state(x, P)
+        ekf.step(u, z, mask)
+        xg, Pg = ekf.get_state()
+        xr, Pr = oracle.run_batch(po, x, P, u[None], z[None], mask[None], per_filter_params=pfp)
+        if dtype == "f64":
+            assert_state_close(xg, Pg, xr, Pr, 1e-11, 1e-13, 1e-11)
+        else:
+            assert_state_close(xg, Pg, xr, Pr, 2e-5, 2e-6, 2e-6)
+        ekf.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("multirate", [0, 1])
+def test_filters_initialise_on_their_own_first_detection(dtype, multirate, kernel_family):
+    """A batch whose filters see their first tag on different ticks (some never): each oracle filter object is seeded by
+    its own first detection (NODE.cpp:169-174 -> EKF.cpp:305-344) and ignored by filter_update until then
+    (EKF.cpp:129-130).  The engine's masked initialize_state + gated filter_update must agree on every tick:
+    untouched zero state and counters before, the same state / correction decisions / upds_since_correction after."""
+    kw = dict(update_freq=100.0, measurement_freq=20.0, limit_measurement_freq=1, corner_margin_enbl=1, direct_orien_method=1,
+              multirate_ekf=multirate, measurement_delay=0.030, dynamic_meas_delay=0)
+    po = oracle.make_params(**kw)
+    rng = np.random.default_rng(99 + multirate)
+    B, T = 80, 36
+    first = rng.integers(0, 24, size=B)
+    first[:5] = 0                      # some from the very first tick
+    first[5:9] = 10 ** 6               # some never see a tag
+    ekf = qla.BatchedRelativePoseEKF(B, dtype, **kw)
+    ekf.enable_gating(True)
+    filt = [oracle.Filter(po) for _ in range(B)]
+    rnd = (lambda a: a.astype(np.float32).astype(np.float64)) if dtype == "f32" else (lambda a: a)
+    pending = np.zeros(B, np.uint8)
+    zlast = np.zeros((B, 7)); zlast[:, 6] = 1
+    inited = np.zeros(B, bool)
+    ekf.initialize_state(zlast, mask=np.zeros(B, np.uint8))     # nothing seeded yet: the handle just accepts ticks
+    n_perf = 0
+    for t in range(T):
+        u = rnd(rand_imu(rng, B) * np.array([0.05, 0.05, 1, 0.2, 0.2, 0.2]))
+        xs = ekf.get_state()[0]
+        # a tag pose near where the filter is (or a plausible first pose for a filter that is not initialised yet)
+        guess = xs.copy()
+        fresh = ~inited
+        guess[fresh, 0:3] = rng.uniform([-0.3, -0.3, 0.9], [0.3, 0.3, 2.2], size=(int(fresh.sum()), 3))
+        guess[fresh, 6:10] = np.array([0, 0, 0, 1.0])
+        znew = rnd(meas_near(rng, po, guess, ang=0.2, pos=0.05))
+        new = (first == t) | (inited & (rng.uniform(size=B) < 0.4))
+        zlast[new] = znew[new]
+        seed_now = new & ~inited
+        for i in range(B):
+            filt[i].set_imu(u[i, :3], u[i, 3:])
+            if new[i]:
+                filt[i].set_apriltag(zlast[i, :3], zlast[i, 3:], 0.01 * t)     # seeds the oracle filter on its first detection
+        if seed_now.any():
+            ekf.initialize_state(zlast, mask=seed_now.astype(np.uint8))
+            if dtype == "f32":   # start the oracle's copy of a freshly seeded filter from the engine's fp32-rounded state
+                xs2, Ps2 = ekf.get_state()
+                for i in np.nonzero(seed_now)[0]:
+                    f = filt[i].f
+                    for k in range(3):
+                        f.r_nom[k] = xs2[i, k]; f.v_nom[k] = xs2[i, 3 + k]; f.ab_nom[k] = xs2[i, 10 + k]; f.wb_nom[k] = xs2[i, 13 + k]
+                    for k in range(4):
+                        f.q_nom[k] = xs2[i, 6 + k]
+                    for k in range(16):
+                        f.x_hist[k] = xs2[i, k]
+            inited |= seed_now
+        pending |= new.astype(np.uint8)
+        for i in range(B):
+            filt[i].filter_update(0.01 * t)
+        ekf.filter_update(u, zlast, pending)
+        perf, cons, upds = ekf.tick_flags()
+        np.testing.assert_array_equal(ekf.state_initialized(), inited.astype(np.uint8))
+        np.testing.assert_array_equal(perf, np.array([f.f.performed_correction for f in filt], np.uint8))
+        np.testing.assert_array_equal(upds, np.array([f.f.upds_since_correction for f in filt], np.int32))
+        pending &= (1 - cons)
+        np.testing.assert_array_equal(pending, np.array([f.f.measurement_ready for f in filt], np.uint8))
+        n_perf += int(perf.sum())
+        xg, Pg = ekf.get_state()
+        assert np.all(xg[~inited] == 0) and np.all(Pg[~inited] == 0)          # never touched
+        if inited.any():
+            xr = np.stack([filt[i].x() for i in np.nonzero(inited)[0]]); Pr = np.stack([filt[i].P() for i in np.nonzero(inited)[0]])
+            if dtype == "f64":
+                assert_state_close(xg[inited], Pg[inited], xr, Pr, 1e-9, 1e-11, 1e-9)
+            else:
+                assert_state_close(xg[inited], Pg[inited], xr, Pr, 2e-3, 2e-3, 2e-3)
+    assert inited.sum() == B - 4 and n_perf > B
+    ekf.close()

@@ -315,13 +315,51 @@ def test_full_filter_update_against_reference_twin(golden_dir, mode):
 
 
 # ---------------- the engine's block-structured algebra, compiled for the CPU, against the dense oracle
-@pytest.mark.parametrize("levels", [True, False])
+def engine_cpu_run(variant, p, x, P, U, Z, M, dtype):
+    """The engine's per-filter arithmetic compiled for the host: one lane per filter (ekf_device.hpp: levelled or
+    in-place predict, sequential decorrelated update) or four lanes per filter on an emulated quad (ekf_quad.hpp)."""
+    if variant == "quad":
+        return oracle.quad_run_batch(p, x, P, U, Z, M, dtype=dtype)
+    return oracle.structured_run_batch(p, x, P, U, Z, M, dtype=dtype, levels=(variant == "levels"))
+
+
+def test_packed_covariance_order_is_a_bijection_with_level_structure():
+    """sidx (ekf_device.hpp) restated: 120 distinct words, block-rows in storage order r, v, th, ab, wb quad-wise,
+    memory quad 3m + l = the m-th quad of quad-lane l, and lane l holds column l of every off-diagonal block."""
+    base = [0, 14, 25, 33, 38]
+
+    def sidx(i, k):
+        i, k = min(i, k), max(i, k)
+        b, c, ii, kk = i // 3, k // 3, i % 3, k % 3
+        if b == c:
+            lane, pos = (kk, base[b]) if ii == kk else ({(0, 1): 1, (1, 2): 2, (0, 2): 0}[(ii, kk)], base[b] + 1)
+        else:
+            lane, pos = kk, base[b] + 2 + 3 * (c - b - 1) + ii
+        return 4 * (3 * (pos // 4) + lane) + pos % 4, lane, pos
+
+    words = {}
+    for i in range(15):
+        for k in range(i, 15):
+            w, lane, pos = sidx(i, k)
+            assert w not in words
+            words[w] = (i, k)
+            assert (w // 4) % 3 == lane and 4 * ((w // 4) // 3) + w % 4 == pos
+            if i // 3 != k // 3:
+                assert lane == k % 3
+    assert sorted(words) == list(range(120))
+    rows = [words[w][0] // 3 for w in range(120)]
+    for q in range(29):   # block-rows never decrease from one quad-row triple to the next
+        assert min(rows[4 * q: 4 * q + 4]) <= min(rows[4 * q + 4: 4 * q + 8]) or q % 3 != 2
+
+
+@pytest.mark.parametrize("variant", ["levels", "inplace", "quad"])
 @pytest.mark.parametrize("direct", [0, 1])
 @pytest.mark.parametrize("est_bias", [0, 1])
-def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, est_bias, levels):
-    """oracle/ekf_structured_cpu.cpp compiles quadrotor_landing_amd/csrc/ekf_device.hpp for the host: the same
-    F = L3 L2 L1 congruences / levelled predict and decorrelated sequential update the HIP kernels run, checked
-    here (no GPU) against the dense reference-shaped restatement over a 60-tick sequence."""
+def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, est_bias, variant):
+    """oracle/ekf_structured_cpu.cpp compiles quadrotor_landing_amd/csrc/ekf_device.hpp and ekf_quad.hpp for the host:
+    the same F = L3 L2 L1 congruences / levelled predict and decorrelated sequential update (one lane per filter) and
+    the column-distributed predict / L D L^T update (four lanes per filter, on an emulated quad) the HIP kernels run,
+    checked here (no GPU) against the dense reference-shaped restatement over a 60-tick sequence."""
     rng = np.random.default_rng(40 + 2 * direct + est_bias)
     p = oracle.make_params(direct_orien_method=direct, est_bias=est_bias, update_freq=400.0, ab_static=[0.2, -0.09, -0.03],
                            wb_static=[-0.02, -0.01, 0.0], q_vc=[-0.7035177, 0.7106742, 0.0014521, -0.0017207],
@@ -351,7 +389,7 @@ def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, 
     xd, Pd = oracle.run_batch(p, x, P, U, Z, M)
     np.testing.assert_allclose(xd, xr, rtol=0, atol=0)  # the incremental construction above is the same computation
     for dtype, tol in (("f64", 1e-10), ("f32", 2e-3)):
-        xs, Ps = oracle.structured_run_batch(p, x, P, U, Z, M, dtype=dtype, levels=levels)
+        xs, Ps = engine_cpu_run(variant, p, x, P, U, Z, M, dtype)
         dqv = np.minimum(np.abs(xs[:, 6:10] - xd[:, 6:10]).max(1), np.abs(xs[:, 6:10] + xd[:, 6:10]).max(1)).max()
         assert dqv < tol, (dtype, dqv)
         keep = [i for i in range(16) if not 6 <= i < 10]
@@ -361,8 +399,8 @@ def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, 
 
 
 @pytest.mark.parametrize("ps", PSETS)
-@pytest.mark.parametrize("levels", [True, False])
-def test_structured_cpu_build_against_reference_twin_sequences(golden_dir, ps, levels):
+@pytest.mark.parametrize("variant", ["levels", "inplace", "quad"])
+def test_structured_cpu_build_against_reference_twin_sequences(golden_dir, ps, variant):
     """The engine's arithmetic (CPU build) against the trajectories the reference's Python twin produced."""
     sets = load_param_sets(golden_dir)
     d = np.load(os.path.join(golden_dir, "sequence_cases.npz"))
@@ -370,8 +408,7 @@ def test_structured_cpu_build_against_reference_twin_sequences(golden_dir, ps, l
     U, Z, M = d[f"{ps}__u"], d[f"{ps}__z"], d[f"{ps}__mask"]
     T = U.shape[0]
     for dtype, tol in (("f64", 1e-9), ("f32", 3e-3)):
-        x, P = oracle.structured_run_batch(p, d[f"{ps}__x_init"][None], d[f"{ps}__P_init"][None], U[:, None, :], Z[:, None, :], M[:, None],
-                                           dtype=dtype, levels=levels)
+        x, P = engine_cpu_run(variant, p, d[f"{ps}__x_init"][None], d[f"{ps}__P_init"][None], U[:, None, :], Z[:, None, :], M[:, None], dtype)
         xr = d[f"{ps}__x_seq"][T - 1]
         assert qclose(x[0, 6:10], xr[6:10], tol * 10)
         np.testing.assert_allclose(np.delete(x[0], range(6, 10)), np.delete(xr, range(6, 10)), rtol=tol, atol=tol)
