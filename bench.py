@@ -1,22 +1,31 @@
 #!/usr/bin/env python3
 """Benchmark of the batched EKF hot path (BASELINE.json metric).
 
-A "step" is one filter tick over the whole batch: one k_predict launch, or on
-every 14th tick one fused k_step launch (BASELINE cfg 3: 65 536 fp32 filters,
-400 Hz IMU predict interleaved with 30 Hz tag update).  Inputs (IMU and tag-pose
-sequences for every tick) are generated on the device beforehand and are
-resident in HBM when the timed region starts.
+A "step" is one filter tick over the whole batch: one predict launch, or on every 14th tick one fused predict+update
+launch (BASELINE cfg 3: 65 536 fp32 filters, 400 Hz IMU predict interleaved with 30 Hz tag update).  Inputs (IMU and
+tag-pose sequences for every tick) are generated on the device beforehand and are resident in HBM when the timed
+region starts.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3|cfg2|cfg4|cfg5|cfg3mr]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU.  Filters are
-sharded across ranks with NO data-path collective (filters are independent);
-torch.distributed (gloo) is used only for the barrier and the max-over-ranks
+N > 1 is launched by torch.distributed.run, one rank per GPU.  Filters are sharded across ranks with NO data-path
+collective (filters are independent); torch.distributed (gloo) is used only for the barrier and the max-over-ranks
 timing.  Rank 0 prints one JSON line.
+
+Workloads (BASELINE.json configs): cfg3 (default, the metric's configuration; weak scaling: 65 536 filters per GPU),
+cfg2 (4 096 fp64 filters, update on every tick), cfg4 (1 048 576 fp32 filters in all, split over the ranks: strong
+scaling), cfg5 (Monte-Carlo sweep, 262 144 filters in all with device-drawn per-filter parameters, split over the ranks,
+per-device RMSE reduction combined on the host; --batch-per-gpu B runs one B-filter shard per rank instead),
+cfg3mr (cfg3 with the multirate delayed-measurement replay).
+
+The K-step timed region is bracketed by barrier + device synchronise on both sides; when it is shorter than ~20 ms it
+is repeated (`repeats`) and the median region (max over ranks of each) is reported, so that `value` does not carry the
+~45 us synchronisation tail of a single sub-millisecond region.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,13 +34,23 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_COPY_GBS = 6290.0       # the same guide's measured float4 streaming-copy rate (79 % of the spec peak)
 
 CFG3 = dict(update_freq=400.0, measurement_freq=30.0, limit_measurement_freq=1, direct_orien_method=1,
             est_bias=1, corner_margin_enbl=1, multirate_ekf=0,
             # noise values of relative_pose_EKF_rotors.yaml:13-19
             Q_a=[0.0005] * 3, Q_w=[0.00005] * 3, Q_ab=[5e-5] * 3, Q_wb=[5e-6] * 3,
             R_r=[0.015, 0.015, 0.020], R_ang=[0.0015, 0.0015, 0.04])
+
+WORKLOADS = {
+    "cfg3": "cfg3: 65536 filters/GPU, 400 Hz IMU predict + 30 Hz tag-pose update (every 14th tick fused), ROTORS noise set",
+    "cfg2": "cfg2: 4096 fp64 filters, predict + update on every tick (100 Hz), ROTORS noise set",
+    "cfg4": "cfg4: 1048576 fp32 filters in all, sharded over the ranks, cfg3 schedule (400 Hz predict + 30 Hz update)",
+    "cfg5": "cfg5: Monte-Carlo sweep, 262144 filters in all sharded over the ranks, per-filter Q scaled by 10^U(-0.5,0.5) and static biases, "
+            "400 Hz predict + 30 Hz update, per-device RMSE reduction",
+    "cfg3mr": "cfg3 with multirate_ekf: 30 Hz tag poses arrive 12 ticks late, corrected in the history ring and replayed",
+}
 
 
 def cpu_share():
@@ -83,6 +102,60 @@ def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
             "single_thread_value": n1 * n_ticks / dt_one, "host_cpus": os.cpu_count()}
 
 
+def head_sha():
+    try:
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
+    except Exception:
+        return None
+
+
+def kernel_name(pol, dtype, step, mr=False, pfp=False):
+    """The kernel a tick of this kind is launched on (ekf_capi.hip: launch_predict / launch_step)."""
+    t = "float" if dtype == "f32" else "double"
+    if mr:
+        return f"k_step_mr<{t}>" if step else f"k_predict<{t},MR>"
+    if pol["coop_ticks"] & (1 if step else 2):
+        return f"kw_tick<{t},{'step' if step else 'predict'}>"
+    return (f"k_step<{t}>" if step else f"k_predict<{t}>") + ("+per-filter-params" if pfp else "")
+
+
+def time_ticks(ekf, seq, t0, n):
+    """n back-to-back ticks of `seq` between HIP events on the launch stream -> microseconds per tick."""
+    ekf.timer_begin()
+    ekf.run(seq, t0, n)
+    return ekf.timer_end() / n * 1e3
+
+
+def sub_record(qla, cfg, B, dtype, upd, n_pred, n_mixed, seed, device):
+    """A second population timed in the same run (rank 0, N = 1): predict-only ticks and the cfg3 mix."""
+    T = upd * 2
+    thm = np.zeros(T, np.uint8); thm[upd - 1::upd] = 1
+    ekf = qla.BatchedRelativePoseEKF(B, dtype, device=device, **cfg)
+    pol = ekf.policy()
+    seq = ekf.make_inputs(T, thm)
+    ekf.synth_generate(seq, seed=seed)
+    ekf.run(seq, 0, T); ekf.synchronize()
+    us_mixed = time_ticks(ekf, seq, 0, n_mixed)
+    n_upd = sum(int(thm[k % T]) for k in range(n_mixed))
+    pseq = ekf.make_inputs(T, None)
+    ekf.synth_generate(pseq, seed=seed + 1)
+    ekf.run(pseq, 0, T); ekf.synchronize()
+    us_pred = time_ticks(ekf, pseq, 0, n_pred)
+    bad = ekf.count_nonfinite()
+    b0, b1 = ekf.algorithmic_bytes(0), ekf.algorithmic_bytes(1)
+    us_step = (us_mixed * n_mixed - us_pred * (n_mixed - n_upd)) / max(n_upd, 1)
+    gbs = b0 / us_pred / 1e3
+    out = {"batch": B, "dtype": dtype, "state_MiB": pol["state_bytes"] / 2 ** 20, "served_by": pol["served_by"],
+           "state_policy": pol["state_policy"], "kernel": kernel_name(pol, dtype, False),
+           "predict_tick_us": us_pred, "achieved": gbs, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "frac_of_measured_copy": gbs / HBM_COPY_GBS,
+           "algorithmic_bytes_per_launch": b0, "launches": n_pred,
+           "mixed_ticks_per_s": B / (us_mixed * 1e-6), "mixed_tick_us": us_mixed, "mixed_ticks": n_mixed,
+           "fused_tick_us_derived": us_step, "fused_tick_achieved": b1 / us_step / 1e3 if us_step > 0 else None,
+           "fused_kernel": kernel_name(pol, dtype, True), "nonfinite_filters": bad}
+    ekf.close()
+    return out
+
+
 def main():
     # stdout carries exactly ONE JSON line (rank 0).  Libraries print there too (gloo announces its peers on
     # stdout), so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
@@ -93,31 +166,34 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4000)
     ap.add_argument("--warmup", type=int, default=60)
-    ap.add_argument("--batch-per-gpu", type=int, default=65536)
+    ap.add_argument("--batch-per-gpu", type=int, default=0, help="filters per rank (weak scaling); default: the workload's own size")
+    ap.add_argument("--global-batch", type=int, default=0, help="filters in all, split over the ranks (strong scaling); default for cfg4 / cfg5")
     ap.add_argument("--dtype", default="f32", choices=["f32", "f64"])
     ap.add_argument("--seq-ticks", type=int, default=0, help="ticks of generated input kept in HBM (0 = steps+warmup, capped)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--predict-only-steps", type=int, default=2000)
-    ap.add_argument("--workload", default="cfg3", choices=["cfg2", "cfg3", "cfg5", "cfg3mr"],
-                    help="cfg3 (default, the metric's configuration); cfg2 = 4096 fp64 filters, update on every tick, 100 Hz; "
-                         "cfg5 = Monte-Carlo sweep: per-filter perturbed Q / static biases, per-device RMSE (32768 filters per GPU); "
-                         "cfg3mr = cfg3 with multirate_ekf (delayed-measurement replay, 30 ms camera latency = 12 ticks)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the hbm_resident / f64_same_batch sub-records and the on-chip-resident variant")
+    ap.add_argument("--kernel-steps", "--predict-only-steps", type=int, default=2000, dest="kernel_steps",
+                    help="back-to-back launches of the dominant kernel for the roofline record")
+    ap.add_argument("--repeats", type=int, default=0, help="repetitions of the K-step timed region (0 = as many as make ~20 ms, at most 25)")
+    ap.add_argument("--workload", default="cfg3", choices=list(WORKLOADS))
     args = ap.parse_args()
     cfg = dict(CFG3)
     upd = 14  # ceil(400/30), relative_pose_EKF.cpp:91
     perturb = False
+    scaling = "weak"
+    per_gpu_default, global_default = 65536, 0
     if args.workload == "cfg2":
         cfg.update(update_freq=100.0, measurement_freq=100.0, limit_measurement_freq=0)
         upd = 1
         args.dtype = "f64"
-        if args.batch_per_gpu == 65536:
-            args.batch_per_gpu = 4096
+        per_gpu_default = 4096
         if args.steps == 4000:
             args.steps, args.warmup = 1000, 20
+    elif args.workload == "cfg4":
+        global_default = 1048576
     elif args.workload == "cfg5":
         perturb = True
-        if args.batch_per_gpu == 65536:
-            args.batch_per_gpu = 32768
+        global_default = 262144
     mr_step = 0
     if args.workload == "cfg3mr":
         # delays of relative_pose_EKF_rotors.yaml:5-7 at 400 Hz: step delay int(0.030/0.0025 + 0.5) = 12 ticks
@@ -140,6 +216,7 @@ def main():
 
     import ctypes
     import quadrotor_landing_amd as qla
+    from quadrotor_landing_amd.sharding import shard_range
 
     ndev = ctypes.c_int32(0)
     qla.lib().qle_device_count(ctypes.byref(ndev))
@@ -147,17 +224,28 @@ def main():
     device = local_rank % max(ndev.value, 1)
     oversubscribed = world > max(ndev.value, 1)
 
-    B, K, W = args.batch_per_gpu, args.steps, args.warmup
-    T = args.seq_ticks or min(K + W, 4200)
+    # which filters this rank owns
+    if args.batch_per_gpu:
+        B, offset, global_batch = args.batch_per_gpu, rank * args.batch_per_gpu, world * args.batch_per_gpu
+    elif args.global_batch or global_default:
+        global_batch = args.global_batch or global_default
+        lo, hi = shard_range(global_batch, rank, world)
+        B, offset = hi - lo, lo
+        scaling = "strong"
+    else:
+        B, offset, global_batch = per_gpu_default, rank * per_gpu_default, world * per_gpu_default
+    K, W = args.steps, args.warmup
+    T = args.seq_ticks or min(K + W, max(140, int(4200 * 65536 / max(B, 1))))   # about 6 GB of fp32 inputs at most
     T = max(upd, (T // upd) * upd)  # whole measurement periods so the wrapped schedule stays periodic
     thm = np.zeros(T, np.uint8); thm[upd - 1::upd] = 1
 
     ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, **cfg)
+    pol = ekf.policy()
     seq = ekf.make_inputs(T, thm)
-    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg5": 0xE4F00005, "cfg3mr": 0xE4F00003}[args.workload]
+    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg4": 0xE4F00003, "cfg5": 0xE4F00005, "cfg3mr": 0xE4F00003}[args.workload]
     if mr_step:
         ekf.set_uniform_measurement_age(mr_step / cfg["update_freq"] - cfg["dyn_measurement_delay_offset"])
-    ekf.synth_generate(seq, seed=seed, filter_offset=rank * B, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
+    ekf.synth_generate(seq, seed=seed, filter_offset=offset, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
     x0 = P0 = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.workload == "cfg3":
         x0, P0 = ekf.get_state()
@@ -166,43 +254,61 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    def timed_region(t_start):
+        """EXACTLY K steps between barrier + device synchronise on both sides -> (wall seconds, HIP-event ms) of this rank."""
+        barrier()
+        ekf.synchronize()
+        t0 = time.perf_counter()
+        ekf.timer_begin()
+        ekf.run(seq, t_start, K)
+        ev = ekf.timer_end()  # HIP events on the launch stream; synchronises
+        ekf.synchronize()
+        w = time.perf_counter() - t0
+        barrier()
+        return w, ev
+
     ekf.run(seq, 0, W)
     ekf.synchronize()
-    barrier()
-    ekf.synchronize()
-    t0 = time.perf_counter()
-    ekf.timer_begin()
-    ekf.run(seq, W, K)
-    ev_ms = ekf.timer_end()  # HIP events on the launch stream; synchronises
-    ekf.synchronize()
-    wall = time.perf_counter() - t0
-    barrier()
+    pos = W
+    regions = [timed_region(pos)]
+    pos += K
+    R = args.repeats or int(min(25, max(1, np.ceil(0.020 / max(regions[0][0], 1e-6)))))
+    if dist is not None:   # every rank must run the same number of regions
+        rt = torch.tensor([R], dtype=torch.int64)
+        dist.all_reduce(rt, op=dist.ReduceOp.MAX)
+        R = int(rt[0])
+    for _ in range(R - 1):
+        regions.append(timed_region(pos))
+        pos += K
+    walls = np.array([r[0] for r in regions]); evs = np.array([r[1] for r in regions])
     if dist is not None:
-        tt = torch.tensor([wall, ev_ms], dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        wall, ev_ms = float(tt[0]), float(tt[1])
+        tt = torch.tensor(np.stack([walls, evs]), dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)      # MAX over ranks, region by region
+        walls, evs = tt[0].numpy(), tt[1].numpy()
+    wall = float(np.median(walls)); ev_ms = float(np.median(evs))
     n_upd = sum(int(thm[(W + k) % T]) for k in range(K))
     bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * ekf.algorithmic_bytes(1)
+    wsz = 4 if args.dtype == "f32" else 8
     if mr_step:
         # multirate correction tick per filter (lazy history, k_step_mr): read u6 + z8 + the entry the measurement
         # belongs to (136) + the (step-1) stored IMU samples in between (8 words each); write the corrected entry (136)
         # and the newest entry (144).  The reference-shaped eager scheme also rewrote the step-1 entries in between.
-        wsz = 4 if args.dtype == "f32" else 8
         words = (6 + 8 + 136 + 8 * (mr_step - 1)) + (136 + 144)
         bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * words * wsz * B
     bad = ekf.count_nonfinite()
-    # per-device error sums vs the generator's truth at the end of the resident sequence (cfg 5 reduction);
-    # meaningful when the run ended on the sequence's last tick, reported in any case
-    rm = ekf.synth_rmse(seq) if (W + K) % T == 0 else None
-    if rm is not None and dist is not None:
-        rt = torch.tensor(rm, dtype=torch.float64)
+    # per-device error sums vs the generator's truth at the end of the resident sequence (cfg 5 reduction): the truth is the
+    # pose after the sequence's last tick, so the (untimed) rest of the current pass is run first
+    ekf.run(seq, pos, (-pos) % T)
+    rm = ekf.synth_rmse(seq)
+    if dist is not None:
+        rt = torch.tensor(list(rm), dtype=torch.float64)
         dist.all_reduce(rt, op=dist.ReduceOp.SUM)   # 3 scalars per device, combined on the host
         rm = rt.numpy()
 
     # separately reported (SURVEY.md section 8(d)(6)): the same K ticks in ONE launch with x and P held in
     # registers (qle_run_resident).  Not the streamed per-tick unit of work; never `value`, never the roofline.
     resident = None
-    if args.workload in ("cfg3", "cfg5") and dist is None:
+    if args.workload in ("cfg3", "cfg5") and dist is None and not args.no_extras:
         ekf.run_resident(seq, 0, upd); ekf.synchronize()
         t1 = time.perf_counter()
         ekf.run_resident(seq, W, K)
@@ -211,49 +317,62 @@ def main():
         resident = {"ticks_per_s": B * K / dt_res, "ms_total": dt_res * 1e3, "launches": 1,
                     "note": "on-chip resident: one launch, state in registers for all K ticks; HBM traffic = inputs only"}
 
-    # dominant kernel (k_predict: 13 of every 14 launches) on its own: the same conditions as the timed
-    # region (a long generated sequence, fresh inputs every tick) minus the fused ticks; HIP events on
-    # the stream the kernel is launched on.  Re-seeds the filters, so it runs after everything else.
-    Kp = args.predict_only_steps
-    Tp = min(Kp, 2000)
-    pseq = ekf.make_inputs(Tp, None)
-    ekf.synth_generate(pseq, seed=seed + 1, filter_offset=rank * B, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
+    # The dominant kernel on its own: the tick kind that carries most of the workload's time (the predict-only tick: 13 of every
+    # 14 launches; cfg2: the fused tick, its only kind), back to back over a long generated sequence with fresh inputs every
+    # tick; HIP events on the stream the kernel is launched on.  Re-seeds the filters, so it runs after everything else.
+    Kp = args.kernel_steps
+    dom_step = upd == 1
+    Tp = min(Kp, max(140, int(2000 * 65536 / max(B, 1))))
+    pseq = ekf.make_inputs(Tp, np.ones(Tp, np.uint8) if dom_step else None)
+    ekf.synth_generate(pseq, seed=seed + 1, filter_offset=offset, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
     ekf.run(pseq, 0, 20)
     ekf.synchronize()
-    ekf.timer_begin()
-    ekf.run(pseq, 20, Kp)
-    p_ms = ekf.timer_end()
-    p_bytes = ekf.algorithmic_bytes(0)
-    p_gbs = p_bytes / (p_ms / Kp * 1e-3) / 1e9
-    traffic = None
+    p_us = time_ticks(ekf, pseq, 20, Kp)
+    p_bytes = ekf.algorithmic_bytes(1 if dom_step else 0)
+    p_gbs = p_bytes / p_us / 1e3
+    traffic = traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tpath) and args.workload == "cfg3" and B == 65536 and args.dtype == "f32":  # measured for this configuration only
+    if os.path.exists(tpath):   # offline PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE are separate runs), keyed by configuration
         try:
-            traffic = json.load(open(tpath)).get("k_predict_hbm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            key = f"{args.workload if args.workload != 'cfg4' else 'cfg3'}:{B}:{args.dtype}:{'step' if dom_step else 'predict'}"
+            if key in tj.get("per_launch", {}):
+                traffic = tj["per_launch"][key]["hbm_bytes"]
+                traffic_src = {"file": "profiles/traffic.json", "measured_at_sha": tj.get("sha"), "kernel": tj["per_launch"][key].get("kernel"),
+                               "note": "2 x FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes (MI355X_MICROARCH.md HBM section); counts "
+                                       "L2<->fabric requests, Infinity-Cache hits included"}
         except Exception:
-            traffic = None
+            traffic = traffic_src = None
 
     out = {
         "metric": "EKF predict+update steps/sec at batch=65536; achieved HBM GB/s vs roofline",
-        "value": world * B * K / wall,
+        "value": global_batch * K / wall,
         "unit": "EKF ticks/s",
-        "n_gpus": world, "steps": K, "warmup": W,
+        "n_gpus": world, "steps": K, "warmup": W, "repeats": R,
         "ms_per_step": wall / K * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
         "dtype": args.dtype, "data": "synthetic",
-        "config": {"workload": {"cfg3": "cfg3: 65536 filters/GPU, 400 Hz IMU predict + 30 Hz tag-pose update (every 14th tick fused), ROTORS noise set",
-                                "cfg2": "cfg2: 4096 fp64 filters, predict + update on every tick (100 Hz), ROTORS noise set",
-                                "cfg5": "cfg5: Monte-Carlo sweep, per-filter Q scaled by 10^U(-0.5,0.5) and static biases, 400 Hz predict + 30 Hz update",
-                                "cfg3mr": "cfg3 with multirate_ekf: 30 Hz tag poses arrive 12 ticks late, corrected in the history ring and replayed"}[args.workload],
-                   "batch_per_gpu": B, "global_batch": world * B, "ticks_resident_in_hbm": T,
+        "config": {"workload": WORKLOADS[args.workload],
+                   "batch_per_gpu": B, "global_batch": global_batch, "ticks_resident_in_hbm": T,
                    "parallelism": f"filters sharded x{world}, no collectives"
                                   + (f" (REHEARSAL: {world} ranks on {ndev.value} device(s))" if oversubscribed else "")},
-        "roofline": {"bound": "hbm", "kernel": "k_predict", "achieved": p_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": p_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                     "algorithmic_bytes_per_launch": p_bytes, "avg_launch_us": p_ms / Kp * 1e3, "launches": Kp,
+        "roofline": {"bound": "hbm", "kernel": kernel_name(pol, args.dtype, dom_step, mr=bool(mr_step), pfp=perturb),
+                     "achieved": p_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": p_gbs / HBM_PEAK_GBS,
+                     "frac_of_measured_copy": p_gbs / HBM_COPY_GBS, "measured_copy_GBs": HBM_COPY_GBS,
+                     "served_by": pol["served_by"],
+                     "served_by_note": {"infinity_cache": "the state (%.0f MiB) stays in the 256 MiB Infinity Cache from tick to tick: this rate is an on-die "
+                                                          "rate and may exceed the HBM copy rate; see hbm_resident for the HBM-served figure" % (pol["ring_bytes"] / 2 ** 20),
+                                        "split": "a fixed part of the state stays in the Infinity Cache, the rest streams from HBM",
+                                        "hbm": "the state streams from HBM every tick"}[pol["served_by"]],
+                     "state_policy": pol["state_policy"], "traffic": traffic, "traffic_source": traffic_src,
+                     "algorithmic_bytes_per_launch": p_bytes, "avg_launch_us": p_us, "launches": Kp,
                      "mixed_achieved": bytes_mixed / (ev_ms * 1e-3) / 1e9,
-                     "mixed_note": f"all K timed launches ({K - n_upd} k_predict : {n_upd} k_step), HIP-event time incl. inter-launch gaps"},
+                     "mixed_kernels": {kernel_name(pol, args.dtype, False, mr=bool(mr_step), pfp=perturb): K - n_upd,
+                                       kernel_name(pol, args.dtype, True, mr=bool(mr_step), pfp=perturb): n_upd},
+                     "mixed_note": "all K timed launches of the median region, HIP-event time incl. inter-launch gaps"},
+        "region_ms": {"median": wall * 1e3, "min": float(walls.min()) * 1e3, "max": float(walls.max()) * 1e3},
         "nonfinite_filters": bad,
+        "head": head_sha(),
     }
     if rm is not None:
         from quadrotor_landing_amd.sharding import combine_rmse
@@ -263,9 +382,13 @@ def main():
         out["on_chip_resident"] = resident
     if x0 is not None:
         out["cpu_baseline"] = cpu_baseline(seq, x0, P0, min(B, 65536), min(140, T))
+    ekf.close()
+    if rank == 0 and world == 1 and args.workload == "cfg3" and not args.no_extras:
+        # the same kernels where the state cannot stay on die, and the reference's own arithmetic type at the headline batch
+        out["hbm_resident"] = sub_record(qla, cfg, 2097152, "f32", upd, 200, 280, 0xE4F00013, device)
+        out["f64_same_batch"] = sub_record(qla, cfg, B, "f64", upd, 400, 560, 0xE4F00023, device)
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
-    ekf.close()
     if dist is not None:
         dist.destroy_process_group()
 

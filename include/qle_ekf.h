@@ -265,6 +265,19 @@ int qle_synchronize(qle_batch *h);
 /* HIP events on the handle's own stream around a timed region. */
 int qle_timer_begin(qle_batch *h);
 int qle_timer_end(qle_batch *h, float *elapsed_ms); /* synchronises */
+/* How this handle launches its ticks (chosen from the batch size and dtype at creation; measurement and reporting only). */
+typedef struct qle_policy {
+    int32_t state_policy;   /* cache policy of the state accesses: 0 cached loads+stores, 1 non-temporal loads, 2 non-temporal
+                               loads+stores, 3 split (a fixed part cached, the rest streamed) */
+    int32_t refresh_period; /* > 0: policy 2 with one cached-store tick every so many ticks (small states) */
+    int32_t split_k64;      /* policy 3: this many of every 64 workgroup groups keep their tiles cached */
+    int32_t block;          /* workgroup size of the one-lane-per-filter kernels */
+    int32_t coop_ticks;     /* bit 0: ticks with tag poses, bit 1: predict-only ticks run on the workgroup-cooperative kernel */
+    int32_t ring_slots;     /* state ring capacity (1 = single-rate, in place) */
+    int64_t state_bytes;    /* bytes of one state slot (144 words x padded batch) */
+    int64_t ring_bytes;     /* state_bytes x ring_slots */
+} qle_policy;
+int qle_get_policy(const qle_batch *h, qle_policy *out);
 /* Algorithmic HBM bytes one launch moves:
  * kind 0 = predict tick, 1 = fused predict+update tick, 2 = stand-alone update. */
 int64_t qle_algorithmic_bytes(const qle_batch *h, int32_t kind);

@@ -55,6 +55,12 @@ class QleSynthCfg(C.Structure):
     ]
 
 
+class QlePolicy(C.Structure):
+    """`struct qle_policy`: how a handle launches its ticks."""
+    _fields_ = [("state_policy", _i32), ("refresh_period", _i32), ("split_k64", _i32), ("block", _i32), ("coop_ticks", _i32),
+                ("ring_slots", _i32), ("state_bytes", _i64), ("ring_bytes", _i64)]
+
+
 class QleError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"qle error {code}: {msg}")
@@ -111,6 +117,7 @@ SYMBOLS = {
     "qle_timer_begin": (C.c_int, [_vp]),
     "qle_timer_end": (C.c_int, [_vp, C.POINTER(C.c_float)]),
     "qle_algorithmic_bytes": (_i64, [_vp, _i32]),
+    "qle_get_policy": (C.c_int, [_vp, C.POINTER(QlePolicy)]),
 }
 
 _lib = None

@@ -285,6 +285,20 @@ extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
     return words * (int64_t)h->wsz * h->B;
 }
 
+extern "C" int qle_get_policy(const qle_batch* h, qle_policy* out)
+{
+    if (!h || !out) return fail(QLE_ERR_INVALID, "null argument");
+    out->state_policy = h->nt;
+    out->refresh_period = (h->nt == 1) ? h->nt_refresh : 0;
+    out->split_k64 = h->nt == 3 ? -h->split : 0;
+    out->block = h->block;
+    out->coop_ticks = h->mr ? 0 : h->quad;
+    out->ring_slots = h->C;
+    out->state_bytes = (int64_t)slot_bytes(h);
+    out->ring_bytes = (int64_t)slot_bytes(h) * h->C;
+    return QLE_OK;
+}
+
 extern "C" int qle_synchronize(qle_batch* h)
 {
     QLE_TRY(check_handle(h));

@@ -288,11 +288,16 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     constexpr int VW = Quad<T>::VW;
     constexpr int NQ = kPW / VW;
     load_P_quads_desc<T, 0, NQ, NT>(src, i, P);
-    if (filter_uninitialised(x)) return;
+    // A filter that is not initialised is left untouched.  No early exit: the compiler would sink the covariance loads below such a
+    // branch and every wave would wait for x before it even issues them (+1 us per tick at 65 536 filters, profiles/r02_tuning.md).
+    // Instead the lane computes on (with a unit quaternion, so that its arithmetic stays finite) and only its stores are masked.
+    const bool dead = filter_uninitialised(x);
+    if (dead) x[9] = T(1);
     T Pn[kPW];
     // a quad is final once every word in it is: first quad that holds only block-rows >= ab / th / v (ekf_device.hpp)
     constexpr int q_ab = level_first_word(3, VW) / VW, q_th = level_first_word(2, VW) / VW, q_v = level_first_word(1, VW) / VW;
     ekf_predict_levels<T>(p, nz, x, P, u, accel, Pn, [&](int level) {
+        if (dead) return;
         if (level == -1) store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
         else if (level == 0) store_P_quads_desc<T, q_ab, NQ, NT>(dst, i, Pn);
         else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(dst, i, Pn);
@@ -301,11 +306,15 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     });
 #else
     load_rec<T, kSW, kXW, kPW, NT>(src, i, P);
-    if (filter_uninitialised(x)) return;
+    const bool dead = filter_uninitialised(x);
+    if (dead) x[9] = T(1);
     ekf_predict<T>(p, nz, x, P, u, accel);
-    store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
-    store_rec<T, kSW, kXW, kPW, NT>(dst, i, P);
+    if (!dead) {
+        store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
+        store_rec<T, kSW, kXW, kPW, NT>(dst, i, P);
+    }
 #endif
+    if (dead) return;
     if (MR) {
         const T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
         store_rec<T, kSW, kUoff, 8, NT>(dst, i, uk);
@@ -353,8 +362,9 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     load_rec<T, kZW, 0, kZW, NT>(zs, i, zr);
     load_rec<T, kSW, 0, kXW, NT>(st, i, x);
     load_P_quads_desc<T, 0, kPW / Quad<T>::VW, NT>(st, i, Po);
-    if (filter_uninitialised(x)) return;
-    bool corr = zr[7] != T(0);
+    const bool dead = filter_uninitialised(x);   // left untouched; no early exit (see predict_tick)
+    if (dead) x[9] = T(1);
+    bool corr = !dead && zr[7] != T(0);
     if (GATE) {  // the mask word means "measurement_ready"; decide here (EKF.cpp:147-186)
         const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
         bool ok = consume;
@@ -369,7 +379,7 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
     ekf_predict_levels<T>(p, nz, x, Po, u, accel, P, [](int) {});
-    if (aux_accel) {  // optional side outputs (wave-uniform), written as soon as they exist
+    if (aux_accel && !dead) {  // optional side outputs (wave-uniform), written as soon as they exist
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
     }
@@ -386,6 +396,7 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
             }
         });
     }
+    if (dead) return;
     store_rec<T, kSW, 0, kXW, NT>(st, i, x);
     store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
 }

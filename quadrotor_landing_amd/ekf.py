@@ -21,7 +21,7 @@ import weakref
 import numpy as np
 
 from . import params as _params
-from ._lib import QLE_F32, QLE_F64, QleSynthCfg, check, lib
+from ._lib import QLE_F32, QLE_F64, QlePolicy, QleSynthCfg, check, lib
 
 _pd = C.POINTER(C.c_double)
 _pu8 = C.POINTER(C.c_uint8)
@@ -281,6 +281,21 @@ class BatchedRelativePoseEKF:
         ms = C.c_float(0)
         check(lib().qle_timer_end(self._h, C.byref(ms)))
         return float(ms.value)
+
+    def policy(self):
+        """How this handle launches its ticks (dict of `struct qle_policy`) plus `served_by`: where the state lives between ticks."""
+        pol = QlePolicy()
+        check(lib().qle_get_policy(self._h, C.byref(pol)))
+        d = {n: int(getattr(pol, n)) for n, _ in QlePolicy._fields_}
+        # 256 MiB Infinity Cache (MI355X_MICROARCH.md): a state ring that fits stays resident from tick to tick under policies 0-2;
+        # the split policy keeps a fixed part resident and streams the rest; anything larger streams from HBM
+        if d["state_policy"] == 3:
+            d["served_by"] = "split"
+        elif d["ring_bytes"] <= 250 * 2 ** 20:
+            d["served_by"] = "infinity_cache"
+        else:
+            d["served_by"] = "hbm"
+        return d
 
     def algorithmic_bytes(self, kind):
         return int(lib().qle_algorithmic_bytes(self._h, int(kind)))

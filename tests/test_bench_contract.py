@@ -16,7 +16,12 @@ def test_cpu_share_and_argument_defaults():
     n = bench.cpu_share()
     assert 1 <= n <= (os.cpu_count() or 1)
     assert bench.CFG3["update_freq"] == 400.0 and bench.CFG3["measurement_freq"] == 30.0
-    assert bench.HBM_PEAK_GBS == 8000.0
+    assert bench.HBM_PEAK_GBS == 8000.0 and bench.HBM_COPY_GBS == 6290.0
+    # the kernel named in the roofline record is the one the workload's dominant tick is launched on
+    lanes = {"coop_ticks": 0}; coop = {"coop_ticks": 1}
+    assert bench.kernel_name(lanes, "f32", False) == "k_predict<float>" and bench.kernel_name(lanes, "f64", True) == "k_step<double>"
+    assert bench.kernel_name(coop, "f64", True) == "kw_tick<double,step>" and bench.kernel_name(coop, "f64", False) == "k_predict<double>"
+    assert bench.kernel_name(lanes, "f32", False, mr=True) == "k_predict<float,MR>"
 
 
 @pytest.mark.gpu
@@ -41,6 +46,17 @@ def test_bench_json_contract(extra):
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) / rf["achieved"] < 1e-6
     assert d["nonfinite_filters"] == 0
+    assert d["repeats"] >= 1 and abs(d["region_ms"]["median"] - d["ms_per_step"] * 42) < 1e-9
+    assert rf["served_by"] in ("infinity_cache", "hbm", "split") and abs(rf["frac_of_measured_copy"] - rf["achieved"] / 6290.0) < 1e-12
+    want_kernel = {"": "k_predict<float>", "cfg5": "k_predict<float>+per-filter-params", "cfg3mr": "k_predict<float,MR>",
+                   "cfg2": "kw_tick<double,step>"}[extra[1] if extra else ""]
+    assert rf["kernel"] == want_kernel, rf["kernel"]
+    assert sum(rf["mixed_kernels"].values()) == 42
+    if not extra:
+        for sub in ("hbm_resident", "f64_same_batch"):
+            assert d[sub]["achieved"] > 0 and d[sub]["nonfinite_filters"] == 0 and d[sub]["served_by"] in ("infinity_cache", "hbm", "split")
+        assert d["hbm_resident"]["batch"] == 2097152 and d["hbm_resident"]["served_by"] == "split"
+        assert d["f64_same_batch"]["dtype"] == "f64" and d["f64_same_batch"]["batch"] == 4096
     if not extra:
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
@@ -65,3 +81,24 @@ def test_bench_two_ranks_print_one_json_line():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["scaling"] == "weak"
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,glob", [("cfg4", 16384), ("cfg5", 8192)])
+def test_bench_strong_scaling_workloads_split_a_fixed_global_batch(workload, glob):
+    """BASELINE cfg 4 / cfg 5 as written: a FIXED population split over the ranks (here 2 ranks on the box's one GPU and a small
+    population; the defaults are 1 048 576 and 262 144 filters)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29543", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "42", "--warmup", "14",
+           "--workload", workload, "--global-batch", str(glob), "--kernel-steps", "60"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == glob and d["config"]["batch_per_gpu"] == glob // 2
+    assert abs(d["value"] - glob / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["nonfinite_filters"] == 0
+    if workload == "cfg5":
+        assert d["rmse_vs_truth"]["filters"] == glob     # the three sums of both devices combined on the host
