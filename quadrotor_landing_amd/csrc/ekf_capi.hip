@@ -120,47 +120,54 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
     if (!p) return fail(QLE_ERR_INVALID, "params is null");
     qle_derived d;
     QLE_TRY(qle_params_derive(p, &d));
-    // State ring: C = 1 (single-rate) or 2 x the largest reachable step delay + 1 (multirate, EKF.cpp:199-201).
-    // Allocate first; the handle's parameters change only once everything needed exists.
+    // The state is one record array, updated in place.  The multirate EKF (EKF.cpp:196-236) keeps its history next to it: an IMU
+    // ring, a state checkpoint every mr_k ticks and one anchor slot (k_step_mr, ekf_kernels.hpp), sized for the largest step delay
+    // the parameters allow (EKF.cpp:199-201).  Everything is allocated into locals; the handle changes only when all of it exists.
     const bool mr = p->multirate_ekf != 0;
-    int32_t C = 1;
+    int32_t Nc = 0, Cu = 0;
     if (mr) {
         int32_t step_max = d.measurement_step_delay;
         if (p->dynamic_meas_delay) step_max = std::max((int32_t)(p->measurement_delay_max / d.dT_nom + 0.5), 1);
-        C = 2 * step_max + 1;   // lazy history (k_step_mr): a measurement in a stale zone restarts from the entry before it
+        Nc = (step_max + h->mr_k + 1 + h->mr_k - 1) / h->mr_k + 1;
+        Cu = Nc * h->mr_k;
     }
-    if (mr && !h->hist_first) {   // allocate everything into locals; the handle changes only when all of it exists
-        int32_t *hf = nullptr, *ff = nullptr;
+    if (!h->ring) {
+        void* nr = nullptr;
+        hipError_t e = hipMalloc(&nr, slot_bytes(h));
+        if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "hipMalloc of the state (%lld filters): %s", (long long)h->Bp, hipGetErrorString(e));
+        e = hipMemsetAsync(nr, 0, slot_bytes(h), h->stream);   // all-zero records = filters not initialised
+        if (e != hipSuccess) { (void)hipFree(nr); return fail(QLE_ERR_HIP, "state setup: %s", hipGetErrorString(e)); }
+        h->ring = nr;
+        h->C = 1;
+    }
+    if (mr && (!h->hist_first || Nc != h->mr_Nc)) {
+        int32_t* hf = nullptr;
         double *stp = nullptr, *dc = nullptr;
+        void *mu = nullptr, *mc = nullptr, *ma = nullptr;
+        const size_t ub = (size_t)Cu * kHW * (size_t)h->Bp * h->wsz, cb = (size_t)Nc * slot_bytes(h);
         hipError_t e = hipMalloc((void**)&hf, sizeof(int32_t) * (size_t)h->Bp);
-        if (e == hipSuccess) e = hipMalloc((void**)&ff, sizeof(int32_t) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMalloc((void**)&stp, sizeof(double) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMalloc((void**)&dc, sizeof(double) * (size_t)h->Bp);
+        if (e == hipSuccess) e = hipMalloc(&mu, ub);
+        if (e == hipSuccess) e = hipMalloc(&mc, cb);
+        if (e == hipSuccess) e = hipMalloc(&ma, slot_bytes(h));
         if (e == hipSuccess) e = hipMemsetAsync(dc, 0, sizeof(double) * (size_t)h->Bp, h->stream);
         if (e == hipSuccess) e = hipMemsetAsync(stp, 0, sizeof(double) * (size_t)h->Bp, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(mu, 0, ub, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(mc, 0, cb, h->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(ma, 0, slot_bytes(h), h->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
         if (e != hipSuccess) {
-            void* tmp[] = {hf, ff, stp, dc};
+            void* tmp[] = {hf, stp, dc, mu, mc, ma};
             for (void* b : tmp)
                 if (b) (void)hipFree(b);
-            return fail(QLE_ERR_NOMEM, "multirate bookkeeping arrays: %s", hipGetErrorString(e));
+            return fail(QLE_ERR_NOMEM, "multirate history (%d checkpoint slots, %d IMU slots x %lld filters): %s", Nc, Cu, (long long)h->Bp, hipGetErrorString(e));
         }
-        h->hist_first = hf; h->fresh_from = ff; h->stamp = stp; h->delay_cur = dc;
-    }
-    if (C != h->C) {
-        void* nr = nullptr;
-        hipError_t e = hipMalloc(&nr, slot_bytes(h) * (size_t)C);
-        if (e != hipSuccess) return fail(QLE_ERR_NOMEM, "hipMalloc of the state ring (%d slots x %lld filters): %s", C, (long long)h->Bp, hipGetErrorString(e));
-        e = hipMemsetAsync(nr, 0, slot_bytes(h) * (size_t)C, h->stream);   // all-zero records = filters not initialised
-        if (e == hipSuccess && h->ring) {  // keep the current state: it moves to the slot the new ring assigns to tick-1
-            int64_t sn = (h->tick - 1) % C;
-            if (sn < 0) sn += C;
-            e = hipMemcpyAsync((char*)nr + slot_bytes(h) * (size_t)sn, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-            if (e == hipSuccess) e = hipFree(h->ring);
-        }
-        if (e != hipSuccess) { (void)hipFree(nr); return fail(QLE_ERR_HIP, "state ring setup: %s", hipGetErrorString(e)); }
-        h->ring = nr;
-        h->C = C;
+        void* old[] = {h->hist_first, h->stamp, h->delay_cur, h->mr_u, h->mr_ckpt, h->mr_anchor};
+        for (void* b : old)
+            if (b) (void)hipFree(b);
+        h->hist_first = hf; h->stamp = stp; h->delay_cur = dc; h->mr_u = mu; h->mr_ckpt = mc; h->mr_anchor = ma;
+        h->mr_Nc = Nc; h->mr_Cu = Cu;
     }
     h->pub = *p;
     h->der = d;
@@ -177,8 +184,8 @@ extern "C" int qle_destroy(qle_batch* h)
     if (!h) return QLE_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    void* bufs[] = {h->ring, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->hist_first, h->fresh_from, h->stamp,
-                    h->delay_cur};
+    void* bufs[] = {h->ring, h->pfp, h->aux_accel, h->aux_obs, h->tick_u, h->tick_z, h->stage, h->stage_mask, h->counter, h->last_corr, h->flags, h->hist_first, h->stamp,
+                    h->delay_cur, h->mr_u, h->mr_ckpt, h->mr_anchor};
     for (void* b : bufs)
         if (b) (void)hipFree(b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -238,6 +245,10 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // (1: ticks with tag poses, 2: predict-only ticks, 0: never).
     h->quad = (dtype == QLE_F64 && batch <= 16384) ? 1 : 0;
     if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
+    // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
+    // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16
+    // -> predict tick 11.7 / 10.9 / 10.4 us, whole schedule 16.1 / 15.1 / 15.1 us per tick; 16 ships (history 0.6 GB).
+    if (const char* s = std::getenv("QLE_MR_K")) h->mr_k = std::min(64, std::max(1, std::atoi(s)));
     if (const char* s = std::getenv("QLE_TICK_REBASE")) {
         const long long v = std::atoll(s);
         if (v >= 16) h->rebase_at = v;
@@ -278,11 +289,12 @@ extern "C" int32_t qle_num_states(const qle_batch* h) { return h ? h->der.num_st
 extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
 {   // packed P, SoA, one streamed tick
     if (!h) return 0;
-    // a multirate predict tick also writes the IMU sample into the new history entry (+6 words, +2 pad)
-    const int64_t wr = (16 + 120) + ((h->mr && kind == 0) ? 8 : 0);
-    int64_t words = kind == 0 ? (16 + 120 + 6) + wr : kind == 1 ? (16 + 120 + 6 + 7) + wr : (16 + 120 + 7) + wr;
+    int64_t words = kind == 0 ? (16 + 120 + 6) + 136 : kind == 1 ? (16 + 120 + 6 + 7) + 136 : (16 + 120 + 7) + 136;
     if (h->pfp_on) words += kFW;
-    return words * (int64_t)h->wsz * h->B;
+    int64_t bytes = words * (int64_t)h->wsz * h->B;
+    // a multirate predict tick also appends to the history: the IMU sample (6 words + 2 pad) and, every mr_k-th tick, a checkpoint
+    if (h->mr && kind == 0) bytes += (int64_t)((kHW + 136.0 / h->mr_k) * (double)h->wsz * (double)h->B);
+    return bytes;
 }
 
 extern "C" int qle_get_policy(const qle_batch* h, qle_policy* out)
@@ -293,9 +305,10 @@ extern "C" int qle_get_policy(const qle_batch* h, qle_policy* out)
     out->split_k64 = h->nt == 3 ? -h->split : 0;
     out->block = h->block;
     out->coop_ticks = h->mr ? 0 : h->quad;
-    out->ring_slots = h->C;
+    out->ring_slots = h->mr ? h->mr_Nc : 1;
     out->state_bytes = (int64_t)slot_bytes(h);
-    out->ring_bytes = (int64_t)slot_bytes(h) * h->C;
+    // what a tick touches again later: the state itself, plus (multirate) the history it streams to
+    out->ring_bytes = (int64_t)slot_bytes(h) * (h->mr ? (2 + h->mr_Nc) : 1) + (h->mr ? (int64_t)h->mr_Cu * kHW * h->Bp * (int64_t)h->wsz : 0);
     return QLE_OK;
 }
 
@@ -482,10 +495,10 @@ extern "C" int qle_get_aux(qle_batch* h, double* accel_rel, double* obs)
 // Restart the multirate history with the single entry "state now" (EKF.cpp:337-339).
 int mr_prepare(qle_batch* h)
 {
-    if (h->mr && h->hist_dirty) {
+    if (h->mr && h->hist_dirty) {   // every filter's history = the single entry "state now": anchor <- state, hist_first = tick-1
         hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->hist_first, (int32_t)(h->tick - 1), h->B);
-        hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->fresh_from, (int32_t)(h->tick - 1), h->B);
         HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h->mr_anchor, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream));
     }
     h->hist_dirty = false;
     return QLE_OK;
@@ -497,7 +510,7 @@ static int launch_predict(qle_batch* h, const void* u)
 {
     if (use_quad(h, 2)) return launch_quad<T>(h, u, nullptr);
     QLE_TRY(mr_prepare(h));
-    return launch_predict_sd<T>(h, u, state_cur(h), state_next(h), h->mr);
+    return launch_predict_sd<T>(h, u, state_cur(h), state_cur(h), h->mr);
 }
 
 
@@ -518,10 +531,10 @@ static int advance_tick(qle_batch* h)
 {
     h->tick++;
     if (h->tick >= h->rebase_at) {
-        const int64_t C = h->C > 0 ? h->C : 1;
-        const int64_t shift = ((h->rebase_at / 2) / C) * C;  // a multiple of C: ring slots (tick % C) are unchanged
+        const int64_t C = h->mr ? h->mr_Cu : 1;
+        const int64_t shift = ((h->rebase_at / 2) / C) * C;  // a multiple of the IMU ring (= k x checkpoint slots): history slots are unchanged
         if (shift <= 0) return QLE_OK;
-        int32_t* arrs[3] = {h->last_corr, h->hist_first, h->fresh_from};
+        int32_t* arrs[2] = {h->last_corr, h->hist_first};
         for (int32_t* a : arrs)
             if (a) {
                 hipLaunchKernelGGL(k_rebase_ticks<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, a, (int32_t)shift, h->B);
@@ -689,7 +702,7 @@ static int seed_t(qle_batch* h, int reinit)
     QLE_TRY(mr_prepare(h));   // a pending whole-batch history restart first; the seeded filters then restart theirs
     hipLaunchKernelGGL((k_seed<T>), grid_for(h, 256), dim3(256), 0, h->stream, dev<T>(h), (const T*)h->tick_z, (T*)state_cur(h),
                        (T)d.cov_init[0], (T)d.cov_init[3], (T)d.cov_init[6], (T)d.cov_init[9], (T)d.cov_init[12], reinit, (int32_t)h->tick,
-                       h->last_corr, h->mr ? h->hist_first : (int32_t*)nullptr, h->mr ? h->fresh_from : (int32_t*)nullptr, h->B);
+                       h->last_corr, h->mr ? h->hist_first : (int32_t*)nullptr, h->mr ? (T*)h->mr_anchor : (T*)nullptr, h->B);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }

@@ -91,7 +91,10 @@ struct qle_batch {
     bool mr = false;               // pub.multirate_ekf
     bool hist_dirty = true;        // state was overwritten: restart the history at the next tick
     int32_t* hist_first = nullptr; // [B] tick of each filter's oldest valid history entry
-    int32_t* fresh_from = nullptr; // [B] tick of the entry written by the filter's last correction tick (entries between are stale)
+    void* mr_u = nullptr;          // IMU ring: mr_Cu slots of kHW words per filter
+    void* mr_ckpt = nullptr;       // state checkpoints: mr_Nc slots, one per mr_k ticks
+    void* mr_anchor = nullptr;     // one state slot: every filter's corrected entry at hist_first
+    int32_t mr_k = 16, mr_Nc = 0, mr_Cu = 0;
     double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
     double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
     double t_curr = 0.0, uniform_age = 0.0;
@@ -157,7 +160,6 @@ static inline void* state_next(const qle_batch* h) { return (char*)h->ring + slo
 static inline int effective_nt(const qle_batch* h)
 {
     if (h->nt == 1 && h->nt_refresh > 0) return (h->tick % h->nt_refresh) == 0 ? 1 : 2;
-    if (h->nt == 3 && h->mr) return 2;   // the split policy is for the in-place single-rate state
     return h->nt;
 }
 
@@ -189,12 +191,15 @@ static inline MrParams make_mr(const qle_batch* h)
 {
     MrParams m;
     std::memset(&m, 0, sizeof(m));
-    m.C = h->C;
+    m.k = h->mr_k;
+    m.Nc = h->mr_Nc;
+    m.Cu = h->mr_Cu;
     m.tick = (int32_t)h->tick;
     m.fixed_step = h->der.measurement_step_delay;
     m.dynamic = h->pub.dynamic_meas_delay;
     m.gate = h->gating ? 1 : 0;
     m.slot_words = (int64_t)kSW * h->Bp;
+    m.u_words = (int64_t)kHW * h->Bp;
     m.dT = h->der.dT_nom;
     m.offset = h->pub.dyn_measurement_delay_offset;
     m.delay_max = h->pub.measurement_delay_max;
@@ -202,13 +207,24 @@ static inline MrParams make_mr(const qle_batch* h)
     m.uniform_age = h->uniform_age;
     return m;
 }
-
+// where tick t's IMU sample goes / where the state after checkpoint tick t goes (nullptr: not a checkpoint tick)
+static inline void* mr_u_slot_host(const qle_batch* h, int64_t t)
+{
+    int64_t s = t % h->mr_Cu;
+    if (s < 0) s += h->mr_Cu;
+    return (char*)h->mr_u + (size_t)s * (size_t)kHW * (size_t)h->Bp * h->wsz;
+}
+static inline void* mr_ck_slot_host(const qle_batch* h, int64_t t)
+{
+    if (t < 0 || t % h->mr_k != 0) return nullptr;
+    return (char*)h->mr_ckpt + slot_bytes(h) * (size_t)((t / h->mr_k) % h->mr_Nc);
+}
 
 // ---- kernel launchers, defined and explicitly instantiated for float and double in the tu_*.hip files ----
 int mr_prepare(qle_batch* h);                                                                  // tu_misc
 template <typename T> int launch_step_mr(qle_batch* h, const void* u, const void* z);          // tu_misc: k_step_mr
 template <typename T> int launch_update(qle_batch* h, const void* z);                          // tu_misc: k_update
 template <typename T> int run_resident_t(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n);   // tu_misc: k_run_resident
-template <typename T> int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u);   // tu_predict: k_predict
+template <typename T> int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool history);   // tu_predict: k_predict
 template <typename T> int launch_step_lane(qle_batch* h, const void* u, const void* z);        // tu_step: k_step
 template <typename T> int launch_quad(qle_batch* h, const void* u, const void* z);             // tu_quad: kw_tick

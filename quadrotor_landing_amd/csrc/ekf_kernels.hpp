@@ -16,9 +16,8 @@
 // The filter state is ONE record of 144 words: x (16), the packed upper triangle of P (120), and
 // the IMU sample that produced it (6 + 2 pad; only written by the multirate EKF, whose history
 // entries are exactly these records).  One lane owns one filter; x and P live in VGPRs for the
-// whole tick.  State storage is a ring of C such record arrays indexed by tick (slot = tick % C):
-// C = 1 for the single-rate filter (updated in place), C = max step delay + 1 for the multirate
-// filter, where the ring IS the history x_hist/u_hist/P_hist of the reference (EKF.hpp:62-64).
+// whole tick and the state is updated in place.  The multirate filter keeps its history next to it (IMU ring, checkpoints,
+// anchors: see k_step_mr); the last 8 words of the record are padding.
 #pragma once
 
 #include "ekf_device.hpp"
@@ -42,6 +41,7 @@ constexpr int kSW = kXW + kPW + 8;  // state record: x, P, u(6) + 2 pad
 constexpr int kUW = 6;      // IMU words
 constexpr int kZW = 8;      // tag pose 7 words + mask word
 constexpr int kFW = 24;     // per-filter parameter words
+constexpr int kHW = 8;      // IMU sample kept in the multirate history: 6 words + 2 pad
 
 // 16-byte quads as native vectors (global_load/store_dwordx4).  NT selects the cache policy of the hot kernels'
 // state accesses: 0 = cached loads and stores (the state lives in the 256 MiB Infinity Cache from tick to tick),
@@ -272,12 +272,14 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 #ifndef QLE_PREDICT_LEVELS
 #define QLE_PREDICT_LEVELS 1
 #endif
-// `src` is the state at tick n-1, `dst` the state at tick n: the same array for the single-rate
-// filter (in place: every load of a lane is issued before its first store), two ring slots for the
-// multirate filter (MR: the record also keeps the IMU sample, EKF.cpp:254-256).
+// `src` is the state at tick n-1, `dst` the state at tick n: the same array (in place: every load of a lane is issued
+// before its first store).  MR (multirate filter): the tick also appends to the history -- the IMU sample goes to its slot
+// of the IMU ring (hist_u, EKF.cpp:254-256) and on checkpoint ticks the new state is copied to its checkpoint slot
+// (hist_ck != nullptr, wave-uniform); see k_step_mr for the history scheme.
 template <typename T, bool PFP, int NT, bool MR>
 __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src, T* dst, const T* __restrict__ us,
-                                             const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t i)
+                                             const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
+                                             T* __restrict__ hist_ck, int64_t i)
 {
     T x[kXW], P[kPW], u[kUW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
@@ -303,6 +305,13 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
         else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(dst, i, Pn);
         else if (level == 2) store_P_quads_desc<T, q_v, q_th, NT>(dst, i, Pn);
         else store_P_quads_desc<T, 0, q_v, NT>(dst, i, Pn);
+        if (MR && hist_ck) {   // checkpoint copy of the same words, streamed
+            if (level == -1) store_rec<T, kSW, 0, kXW, 2>(hist_ck, i, x);
+            else if (level == 0) store_P_quads_desc<T, q_ab, NQ, 2>(hist_ck, i, Pn);
+            else if (level == 1) store_P_quads_desc<T, q_th, q_ab, 2>(hist_ck, i, Pn);
+            else if (level == 2) store_P_quads_desc<T, q_v, q_th, 2>(hist_ck, i, Pn);
+            else store_P_quads_desc<T, 0, q_v, 2>(hist_ck, i, Pn);
+        }
     });
 #else
     load_rec<T, kSW, kXW, kPW, NT>(src, i, P);
@@ -312,12 +321,16 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     if (!dead) {
         store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
         store_rec<T, kSW, kXW, kPW, NT>(dst, i, P);
+        if (MR && hist_ck) {
+            store_rec<T, kSW, 0, kXW, 2>(hist_ck, i, x);
+            store_rec<T, kSW, kXW, kPW, 2>(hist_ck, i, P);
+        }
     }
 #endif
     if (dead) return;
     if (MR) {
-        const T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
-        store_rec<T, kSW, kUoff, 8, NT>(dst, i, uk);
+        const T uk[kHW] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+        store_rec<T, kHW, 0, kHW, 2>(hist_u, i, uk);
     }
     if (aux_accel) {  // optional side output (wave-uniform), AoS [B][3] in the compute dtype
 #pragma unroll
@@ -336,15 +349,16 @@ __device__ __forceinline__ bool cached_workgroup(int32_t split)
 
 template <typename T, bool PFP, int NT, bool MR>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
-                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, int64_t B, int32_t split)
+                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
+                                                       T* __restrict__ hist_ck, int64_t B, int32_t split)
 {
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {
-        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR>(p, src, dst, us, pfp, aux_accel, i);
-        else predict_tick<T, PFP, 2, MR>(p, src, dst, us, pfp, aux_accel, i);
+        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, i);
+        else predict_tick<T, PFP, 2, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, i);
     } else {
-        predict_tick<T, PFP, NT, MR>(p, src, dst, us, pfp, aux_accel, i);
+        predict_tick<T, PFP, NT, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, i);
     }
 }
 
@@ -418,49 +432,60 @@ __global__ __launch_bounds__(kBlock) void k_step(DevParams<T> p, GateParams gp, 
 }
 
 // ------------------------------------------------------------ multirate EKF
-// filter_update with multirate_ekf = true (EKF.cpp:196-236, 251-264): a tag pose that was taken
-// `step` ticks ago is fused into the state the filter held THEN, and the predictions since are
-// replayed with the stored IMU samples.
+// filter_update with multirate_ekf = true (EKF.cpp:196-236, 251-264): a tag pose that was taken `step` ticks ago is fused
+// into the state the filter held THEN, and the predictions since are replayed with the stored IMU samples.
 //
-// History: the reference keeps per-filter vectors x_hist/u_hist/P_hist (EKF.hpp:62-64) whose
-// entries belong to consecutive ticks.  Here the entry "state after tick n" of every filter is
-// the state record in ring slot n % C, so the history costs nothing extra on predict-only ticks
-// (k_predict<MR> reads slot n-1 and writes slot n) and filters with equal delays read the same
-// slot and stay coalesced.  Per filter only hist_first[i], the tick of its oldest valid entry,
-// is kept; it changes only on corrections (the trim of EKF.cpp:214-219).  The index the
-// reference computes, ind = max(len - step, 0) (EKF.cpp:201), never reaches further back than
-// step_max = the largest step delay the parameters allow, so a ring of C = step_max + 1 slots
-// reproduces the unbounded vectors exactly (older entries are unreachable).
+// History.  The reference keeps per-filter vectors x_hist / u_hist / P_hist (EKF.hpp:62-64) with one entry per tick; only
+// the entry `step` ticks back (at most step_max) and its successors are ever read again, and after a correction the history
+// starts at the corrected entry (the trim of EKF.cpp:214-219).  "State after tick t" is a pure function of an earlier state of
+// the same chain and the IMU samples in between, so the engine stores
+//   cur      the state after the newest tick, in place (one record array, cache-resident exactly like the single-rate filter);
+//   u ring   the IMU sample of every tick, slot t % Cu (8 words per filter and tick);
+//   ckpt     a copy of the state after every k-th tick, slot (t/k) % Nc (Cu = k Nc >= step_max + k + 1);
+//   anchor   per filter the corrected entry of its last correction (tick hist_first[i]) -- the start of its history;
+// and rebuilds the entry a measurement belongs to by replaying at most k-1 predictions from the newest checkpoint in
+// (hist_first, mt], or from the anchor.  The replay towards "now" rewrites the checkpoints it passes, so every checkpoint
+// newer than hist_first always holds the current chain.  Same arithmetic on the same stored samples as the reference's
+// rewritten history entries, hence the same values; a predict-only tick costs 8 + 136/k extra words instead of a second copy
+// of the state, and the history of 65 536 fp32 filters at 400 Hz with a 200 ms window is 0.75 GB instead of 6 GB.
 struct MrParams {
-    int32_t C;            // ring capacity (slots)
-    int32_t tick;         // index n of this tick; the newest history entry is tick n-1
+    int32_t k;            // checkpoint period in ticks
+    int32_t Nc;           // checkpoint slots
+    int32_t Cu;           // IMU ring slots = k * Nc
+    int32_t tick;         // index n of this tick; the newest history entry is tick n-1 (= cur)
     int32_t fixed_step;   // measurement_step_delay (EKF.cpp:93) when !dynamic
     int32_t dynamic;      // dynamic_meas_delay (EKF.hpp:79)
     int32_t gate;         // 1: mask word = measurement_ready, decide on device; 0: mask word = perform
     int32_t _pad;
-    int64_t slot_words;   // words per ring slot
+    int64_t slot_words;   // words per state slot (kSW x padded batch)
+    int64_t u_words;      // words per IMU ring slot (kHW x padded batch)
     double dT, offset, delay_max, t_curr, uniform_age;  // EKF.cpp:199-200
 };
 
+__host__ __device__ inline int32_t floor_div(int32_t a, int32_t b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 template <typename T>
-__device__ __forceinline__ T* ring_slot(T* ring, const MrParams& m, int32_t tick)
+__device__ __forceinline__ T* mr_u_slot(T* uring, const MrParams& m, int32_t tick)
 {
-    int32_t s = tick % m.C;
-    if (s < 0) s += m.C;
-    return ring + (int64_t)s * m.slot_words;
+    int32_t s = tick % m.Cu;
+    if (s < 0) s += m.Cu;
+    return uring + (int64_t)s * m.u_words;
+}
+template <typename T>
+__device__ __forceinline__ T* mr_ck_slot(T* ckpt, const MrParams& m, int32_t tick)   // tick is a multiple of k, >= 0
+{
+    return ckpt + (int64_t)((tick / m.k) % m.Nc) * m.slot_words;
 }
 
-// A multirate tick that carries tag poses.  Lanes that correct: load history entry tick_m, fuse the
-// measurement there, replay the predictions tick_m+1 .. n-1 from the stored IMU samples, then predict
-// tick n.  Lanes that do not: plain predict from entry n-1.  One predict call site serves the replay
-// and the current tick: iteration k uses the IMU sample stored in entry base+k, the last iteration the
-// current sample.
+// A multirate tick that carries tag poses.  Lanes that correct: load the newest checkpoint at or before the entry the
+// measurement belongs to (or the anchor), replay up to that entry, fuse the measurement there (the corrected entry becomes the
+// anchor), replay the predictions up to n-1 from the stored IMU samples -- rewriting the checkpoints on the way -- then predict
+// tick n.  Lanes that do not: plain predict of `cur`.  One predict call site serves the replay and the current tick.
 template <typename T, bool DIRECT, bool PFP>
-__global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* ring, const T* __restrict__ us,
-                                                    const T* __restrict__ zs, const T* __restrict__ pfp, const double* __restrict__ stamp,
-                                                    T* __restrict__ aux_accel, T* __restrict__ aux_obs, int32_t* __restrict__ hist_first,
-                                                    int32_t* __restrict__ fresh_from, int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, double* __restrict__ delay_out,
-                                                    int64_t B)
+__global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* cur, T* uring, T* ckpt, T* anchor,
+                                                    const T* __restrict__ us, const T* __restrict__ zs, const T* __restrict__ pfp,
+                                                    const double* __restrict__ stamp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
+                                                    int32_t* __restrict__ hist_first, int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags,
+                                                    double* __restrict__ delay_out, int64_t B)
 {
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
@@ -470,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     load_noise<T, PFP>(p, pfp, i, nz);
     T zr[kZW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
-    load_rec<T, kSW, 0, kXW>(ring_slot(ring, m, m.tick - 1), i, x);   // newest entry: is the filter initialised at all?
+    load_rec<T, kSW, 0, kXW>(cur, i, x);
     if (filter_uninitialised(x)) return;
     bool corr = zr[7] != T(0);
     if (m.gate) {  // EKF.cpp:147-186
@@ -484,15 +509,8 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         if (ok) last_corr[i] = gp.tick;
         flags[i] = (uint8_t)((ok ? 1 : 0) | (consume ? 2 : 0));
     }
-    // Lazy history.  The reference re-predicts from the corrected entry to now and REWRITES every history entry on
-    // the way (EKF.cpp:222-226).  Those rewritten entries are read again only if a later measurement belongs to one of
-    // them, so here only the corrected entry and the newest one are written; the entries in between stay stale and
-    // are recomputed from the corrected entry (same arithmetic, same stored IMU samples -> same values) if that
-    // happens.  Per filter: hist_first = tick of the corrected (oldest valid) entry, fresh_from = tick of the entry
-    // written by that correction tick; entries strictly between the two are stale, everything from fresh_from on
-    // is the predict chain built on it.  A measurement tick mt in the stale zone starts from hist_first, so the ring
-    // holds 2 * step_max + 1 entries (qle_set_params).
     int32_t start = m.tick - 1, mt = 0;    // entry the chain starts from; tick the measurement belongs to (if corr)
+    const T* sp = cur;
     if (corr) {
         // EKF.cpp:199-201: delay -> step delay -> history entry the measurement belongs to
         int32_t step = m.fixed_step;
@@ -504,21 +522,18 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
             if (step < 1) step = 1;
         }
         const int32_t first = hist_first[i];
-        int32_t len = m.tick - first;          // entries hist_first .. n-1
-        if (len > m.C) len = m.C;              // older ones have been overwritten and are unreachable
+        const int32_t len = m.tick - first;    // entries first .. n-1
         int32_t ind = len - step;
         if (ind < 0) ind = 0;
-        mt = (m.tick - len) + ind;
-        start = (mt > first && mt < fresh_from[i]) ? first : mt;
+        mt = first + ind;
+        const int32_t c0 = floor_div(mt, m.k) * m.k;   // newest checkpoint tick <= mt
+        if (c0 > first) { start = c0; sp = mr_ck_slot(ckpt, m, c0); }
+        else { start = first; sp = anchor; }
         hist_first[i] = mt;                    // EKF.cpp:214-219
-        fresh_from[i] = m.tick;
     }
-    {
-        const T* sp = ring_slot(ring, m, start);
-        load_rec<T, kSW, 0, kXW>(sp, i, x);
-        load_rec<T, kSW, kXW, kPW>(sp, i, P);
-    }
-    for (int32_t t = start;; ) {
+    if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
+    load_rec<T, kSW, kXW, kPW>(sp, i, P);
+    for (int32_t t = start;;) {
         if (corr && t == mt) {                                // the entry the measurement belongs to
             const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
             ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&o)[7]) {   // EKF.cpp:209
@@ -527,21 +542,24 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
                     for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
                 }
             });
-            T* sm = ring_slot(ring, m, t);
-            store_rec<T, kSW, 0, kXW>(sm, i, x);              // EKF.cpp:210-211
-            store_rec<T, kSW, kXW, kPW>(sm, i, P);
+            store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
+            store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
         }
         if (t == m.tick) break;
         ++t;                                                  // EKF.cpp:222-226, then :249
-        T* sk = ring_slot(ring, m, t);
-        T uk[8] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
-        if (t != m.tick) load_rec<T, kSW, kUoff, 8>(sk, i, uk);
+        T uk[kHW] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+        if (t != m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t), i, uk);
         const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
         ekf_predict<T>(p, nz, x, P, u6, accel);
         if (t == m.tick) {
-            store_rec<T, kSW, 0, kXW>(sk, i, x);
-            store_rec<T, kSW, kXW, kPW>(sk, i, P);
-            store_rec<T, kSW, kUoff, 8>(sk, i, uk);           // EKF.cpp:254-256
+            store_rec<T, kSW, 0, kXW>(cur, i, x);
+            store_rec<T, kSW, kXW, kPW>(cur, i, P);
+            store_rec<T, kHW, 0, kHW, 2>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
+        }
+        if (t % m.k == 0 && (t == m.tick || (corr && t > mt))) {   // checkpoints of the rewritten part of the chain
+            T* ck = mr_ck_slot(ckpt, m, t);
+            store_rec<T, kSW, 0, kXW, 2>(ck, i, x);
+            store_rec<T, kSW, kXW, kPW, 2>(ck, i, P);
         }
     }
     if (aux_accel) {
@@ -713,7 +731,7 @@ __global__ void k_unpack_P_off(const T* __restrict__ st, int n, double* __restri
 template <typename T>
 __global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__ st, T cov0, T cov1, T cov2, T cov3, T cov4,
                        int reinit_bias, int32_t tick, int32_t* __restrict__ last_corr, int32_t* __restrict__ hist_first,
-                       int32_t* __restrict__ fresh_from, int64_t B)
+                       T* __restrict__ anchor, int64_t B)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
@@ -747,7 +765,11 @@ __global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__
     store_rec<T, kSW, 0, kXW>(st, i, x);
     store_rec<T, kSW, kXW, kPW>(st, i, P);
     if (fresh && last_corr) last_corr[i] = tick - 1;
-    if (hist_first) { hist_first[i] = tick - 1; fresh_from[i] = tick - 1; }
+    if (hist_first) {   // multirate: the history is the single entry "state now" (EKF.cpp:337-339)
+        hist_first[i] = tick - 1;
+        store_rec<T, kSW, 0, kXW>(anchor, i, x);
+        store_rec<T, kSW, kXW, kPW>(anchor, i, P);
+    }
 }
 
 // What the node publishes after a tick (NODE.cpp:192-220), AoS fp64, one chunk.

@@ -9,17 +9,20 @@
 
 // prediction_step from `src` into `dst`; keep_u: the record also stores the IMU sample (multirate history).
 template <typename T>
-int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool keep_u)
+int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool history)
 {
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
     T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, h->B, h->split)
+    // multirate history of this tick: the IMU sample's ring slot and, on checkpoint ticks, the checkpoint slot
+    T* hu = history ? (T*)mr_u_slot_host(h, h->tick) : (T*)nullptr;
+    T* hc = history ? (T*)mr_ck_slot_host(h, h->tick) : (T*)nullptr;
+#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, h->B, h->split)
 #define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
     const int nt = effective_nt(h);
 #define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)
-    if (keep_u) QLE_PRED_M(true);
+    if (history) { if (nt == 3) QLE_PRED_N(3, true); else QLE_PRED_M(true); }
     else if (nt == 3) QLE_PRED_N(3, false);
     else QLE_PRED_M(false);
 #undef QLE_PRED_M
