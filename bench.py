@@ -103,6 +103,8 @@ def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
 
 
 def head_sha():
+    if os.environ.get("QLE_HEAD_SHA"):     # the GPU box's snapshot has no .git: the profiling script exports the head it was made from
+        return os.environ["QLE_HEAD_SHA"]
     try:
         return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip() or None
     except Exception:
