@@ -289,9 +289,12 @@ class BatchedRelativePoseEKF:
         d = {n: int(getattr(pol, n)) for n, _ in QlePolicy._fields_}
         # 256 MiB Infinity Cache (MI355X_MICROARCH.md): a state ring that fits stays resident from tick to tick under policies 0-2;
         # the split policy keeps a fixed part resident and streams the rest; anything larger streams from HBM
-        if d["state_policy"] == 3:
+        # "split": part of what a tick touches is served on die, part by HBM -- the cached / streamed split policy, a state a
+        # little larger than the cache under the cached policy, or the multirate filter (state on die, history streamed to HBM)
+        cache = 250 * 2 ** 20
+        if d["state_policy"] == 3 or (d["ring_bytes"] > cache and (d["state_bytes"] <= cache or d["state_policy"] == 0)):
             d["served_by"] = "split"
-        elif d["ring_bytes"] <= 250 * 2 ** 20:
+        elif d["ring_bytes"] <= cache:
             d["served_by"] = "infinity_cache"
         else:
             d["served_by"] = "hbm"
