@@ -51,7 +51,7 @@ __device__ __forceinline__ void t_sincos(double v, double* s, double* c) { sinco
 // with base = {0, 14, 25, 33, 38}; word = 4 (3 (pos/4) + lane) + pos%4.
 __host__ __device__ constexpr int quad_group_base(int b) { return b == 0 ? 0 : b == 1 ? 14 : b == 2 ? 25 : b == 3 ? 33 : 38; }
 __host__ __device__ constexpr int quad_word(int lane, int pos) { return 4 * (3 * (pos / 4) + lane) + pos % 4; }
-__host__ __device__ constexpr int sidx(int i, int j)
+__host__ __device__ constexpr int sidx_formula(int i, int j)
 {
     const int lo = i <= j ? i : j, hi = i <= j ? j : i;
     const int b = lo / 3, c = hi / 3, ii = lo % 3, kk = hi % 3;
@@ -60,6 +60,26 @@ __host__ __device__ constexpr int sidx(int i, int j)
         return quad_word((ii == 0 && kk == 1) ? 1 : (ii == 1 && kk == 2) ? 2 : 0, quad_group_base(b) + 1);
     }
     return quad_word(kk, quad_group_base(b) + 2 + 3 * (c - b - 1) + ii);
+}
+// Device code folds the formula (every index is a compile-time constant after unrolling); host builds of this header (the
+// test-only CPU build of the engine's arithmetic) look it up in a table instead of evaluating the divisions at run time.
+struct SidxTable { unsigned char v[15][15]; };
+constexpr SidxTable make_sidx_table()
+{
+    SidxTable t{};
+    for (int i = 0; i < 15; ++i)
+        for (int j = 0; j < 15; ++j) t.v[i][j] = (unsigned char)sidx_formula(i, j);
+    return t;
+}
+template <int Dummy = 0> struct SidxHolder { static constexpr SidxTable table = make_sidx_table(); };
+template <int Dummy> constexpr SidxTable SidxHolder<Dummy>::table;
+__host__ __device__ constexpr int sidx(int i, int j)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return sidx_formula(i, j);
+#else
+    return SidxHolder<>::table.v[i][j];
+#endif
 }
 // Block-row (0 = r ... 4 = wb) of the element stored in word w.
 __host__ __device__ constexpr int word_block_row(int w)
