@@ -238,12 +238,13 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(3, std::max(0, std::atoi(s)));
         if (const char* s = std::getenv("QLE_SPLIT")) h->split = std::atoi(s);
     }
-    // Workgroup-cooperative tick kernel (ekf_quad_kernels.hpp: a scalar wave + covariance quads, 45 covariance values per lane).
-    // Measured (profiles/r02_tuning.md): it wins where the one-lane-per-filter kernel spills and the chip is not full -- fp64 ticks
-    // that carry corrections up to 16 384 filters (BASELINE cfg 2: 13.9 vs 18.9 us per tick at 4 096 filters) -- and loses elsewhere
-    // (fp32 at 65 536 filters 25 vs 14.7 us, fp64 60 vs 38 us), so it is selected only there.  QLE_QUAD=bits overrides
-    // (1: ticks with tag poses, 2: predict-only ticks, 0: never).
-    h->quad = (dtype == QLE_F64 && batch <= 16384) ? 1 : 0;
+    // Workgroup-cooperative tick kernel (ekf_quad_kernels.hpp: scalar waves + covariance quads, 45 covariance values per lane).
+    // Measured (profiles/r02_tuning.md section 2): it wins on ticks that carry corrections while the chip is not full -- up to 16 384
+    // filters in both dtypes (fp64 4 096 filters, BASELINE cfg 2: 12.9 vs 18.9 us per tick; fp32: 8.2 vs 9.5 us) -- and loses beyond
+    // (32 768 filters: fp32 13.0 vs 12.0 us, fp64 28.2 vs 25.5; 65 536: 25 vs 14.7 and 60 vs 38), so it is selected only there and
+    // only for ticks with tag poses (predict-only ticks take the same time on both).  QLE_QUAD=bits overrides (1: ticks with tag
+    // poses, 2: predict-only ticks, 0: never).
+    h->quad = batch <= 16384 ? 1 : 0;
     if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
     // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
     // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16

@@ -420,19 +420,51 @@ __host__ __device__ __forceinline__ void predict_P(const DevParams<T>& p, const 
 }
 
 // ----------------------------------------------------------- update, scalar
-// correction_step up to the gain (EKF.cpp:417-475) for one filter: innovation, G, R_k, S = G P G^T + R_k = L D L^T.
-// Frr / Frt / Ftt: the predicted covariance blocks (r,r), (r,th), (th,th), full 3x3 row-major.  x is not changed
-// (update_inject applies the error state).  emit_obs(obs): r_t_vt_obs(3), q_tv_obs(4) (EKF.cpp:431-443).
+// correction_step up to the gain (EKF.cpp:417-475) for one filter, in three parts so that the kernel can run the first two on
+// other waves while wave 0 is still busy with the predict's scalar part (they need the predicted nominal state only):
+//   update_innovation  dy = [r_obs - r; log(conj(q) (x) q_obs)]                     (EKF.cpp:429-450)
+//   update_noise       Gx = Cc [Cc^T r]x (conventional method), R_k = N R N^T       (EKF.cpp:453-472)
+//   update_factor      S = G P G^T + R_k = L D L^T, yd = D^-1 L^-1 dy               (EKF.cpp:475 in factored form)
+// x is the PREDICTED nominal state and is not changed (update_inject applies the error state).
+constexpr int kRkWords = 21;   // upper triangle of the 6x6 R_k, row-major
+__host__ __device__ constexpr int rk_idx(int i, int j) { return i * 6 - i * (i - 1) / 2 + (j - i); }   // i <= j
+
+// The nominal-state propagation alone (EKF.cpp:356-371): what the other waves need of the predict.
+template <class Q, typename T>
+__host__ __device__ __forceinline__ void predict_nominal(const DevParams<T>& p, const NoiseV<typename Q::V>& nz, typename Q::V (&x)[16],
+                                                         const typename Q::V (&u)[6])
+{
+    using V = typename Q::V;
+    const V dT = V(p.dT);
+    V a[3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        a[i] = u[i] - x[10 + i] - nz.ab_static[i];
+        w[i] = u[3 + i] - x[13 + i] - nz.wb_static[i];
+    }
+    V q[4] = {x[6], x[7], x[8], x[9]};
+    V C[9];
+    q_to_rot(q, C);
+    V dw[3] = {dT * w[0], dT * w[1], dT * w[2]}, qe[4], qn[4];
+    q_exp<Q>(dw, qe);
+    q_mul(q, qe, qn);
+    q_norm<Q>(qn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const V acc = (C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]) + V(p.g[i]);
+        x[i] = x[i] + dT * x[3 + i];
+        x[3 + i] = x[3 + i] + dT * acc;
+    }
+    x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+}
+
 template <class Q, typename T, bool DIRECT, typename EmitObs>
-__host__ __device__ __forceinline__ void update_scalar(const DevParams<T>& p, const NoiseV<typename Q::V>& nz, const typename Q::V (&x)[16],
-                                                       const typename Q::V (&z)[7], const typename Q::V (&Frr)[9], const typename Q::V (&Frt)[9],
-                                                       const typename Q::V (&Ftt)[9], UpdU<typename Q::V>& o, EmitObs&& emit_obs)
+__host__ __device__ __forceinline__ void update_innovation(const DevParams<T>& p, const typename Q::V (&x)[16], const typename Q::V (&z)[7],
+                                                           typename Q::V (&dy)[6], EmitObs&& emit_obs)
 {
     using V = typename Q::V;
     V q[4] = {x[6], x[7], x[8], x[9]};
     V r[3] = {x[0], x[1], x[2]};
-    V Cc[9];
-    q_to_rot(q, Cc);                                         // EKF.cpp:429
     V qo[4];
     {
         V qvc[4] = {V(p.q_vc[0]), V(p.q_vc[1]), V(p.q_vc[2]), V(p.q_vc[3])};
@@ -441,35 +473,40 @@ __host__ __device__ __forceinline__ void update_scalar(const DevParams<T>& p, co
         qo[0] = -t[0]; qo[1] = -t[1]; qo[2] = -t[2]; qo[3] = t[3];
         q_norm<Q>(qo);                                       // EKF.cpp:432
     }
-    V dy[6];
-    {
-        V Cq[9];
-        if (DIRECT) q_to_rot(qo, Cq);                        // EKF.cpp:434-444
-        else {
+    V Cq[9];
+    if (DIRECT) q_to_rot(qo, Cq);                            // EKF.cpp:434-444
+    else q_to_rot(q, Cq);
+    V pv[3], obs[7];
 #pragma unroll
-            for (int i = 0; i < 9; ++i) Cq[i] = Cc[i];
-        }
-        V pv[3], obs[7];
+    for (int i = 0; i < 3; ++i)
+        pv[i] = (V(p.C_vc[3 * i]) * z[0] + V(p.C_vc[3 * i + 1]) * z[1] + V(p.C_vc[3 * i + 2]) * z[2]) + V(p.r_v_cv[i]);
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-            pv[i] = (V(p.C_vc[3 * i]) * z[0] + V(p.C_vc[3 * i + 1]) * z[1] + V(p.C_vc[3 * i + 2]) * z[2]) + V(p.r_v_cv[i]);
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            V ro = -(Cq[3 * i] * pv[0] + Cq[3 * i + 1] * pv[1] + Cq[3 * i + 2] * pv[2]);
-            obs[i] = ro;
-            dy[i] = ro - r[i];                               // EKF.cpp:447
-        }
-        obs[3] = qo[0]; obs[4] = qo[1]; obs[5] = qo[2]; obs[6] = qo[3];
-        emit_obs(obs);
-        V qc[4] = {-q[0], -q[1], -q[2], q[3]}, dq[4], dth[3];
-        q_mul(qc, qo, dq);                                   // EKF.cpp:448
-        q_norm<Q>(dq);                                       // EKF.cpp:449
-        q_log<Q>(dq, dth);                                   // EKF.cpp:450
-        dy[3] = dth[0]; dy[4] = dth[1]; dy[5] = dth[2];
+    for (int i = 0; i < 3; ++i) {
+        V ro = -(Cq[3 * i] * pv[0] + Cq[3 * i + 1] * pv[1] + Cq[3 * i + 2] * pv[2]);
+        obs[i] = ro;
+        dy[i] = ro - r[i];                                   // EKF.cpp:447
     }
+    obs[3] = qo[0]; obs[4] = qo[1]; obs[5] = qo[2]; obs[6] = qo[3];
+    emit_obs(obs);
+    V qc[4] = {-q[0], -q[1], -q[2], q[3]}, dq[4], dth[3];
+    q_mul(qc, qo, dq);                                       // EKF.cpp:448
+    q_norm<Q>(dq);                                           // EKF.cpp:449
+    q_log<Q>(dq, dth);                                       // EKF.cpp:450
+    dy[3] = dth[0]; dy[4] = dth[1]; dy[5] = dth[2];
+}
+
+template <class Q, typename T, bool DIRECT>
+__host__ __device__ __forceinline__ void update_noise(const DevParams<T>& p, const NoiseV<typename Q::V>& nz, const typename Q::V (&x)[16],
+                                                      typename Q::V (&Gx)[9], typename Q::V (&Rk)[kRkWords])
+{
+    using V = typename Q::V;
+    V q[4] = {x[6], x[7], x[8], x[9]};
+    V r[3] = {x[0], x[1], x[2]};
+    V Cc[9];
+    q_to_rot(q, Cc);                                         // EKF.cpp:429
     // G = [I Gx; 0 I] over the columns {r, th}; Gx = Cc [Cc^T r]x unless direct (EKF.cpp:453-459)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o.Gx[k] = V(0);
+    for (int k = 0; k < 9; ++k) Gx[k] = V(0);
     if (!DIRECT) {
         V b[3];
 #pragma unroll
@@ -477,69 +514,93 @@ __host__ __device__ __forceinline__ void update_scalar(const DevParams<T>& p, co
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             V c0 = Cc[3 * i], c1 = Cc[3 * i + 1], c2 = Cc[3 * i + 2];
-            o.Gx[3 * i] = c1 * b[2] - c2 * b[1];
-            o.Gx[3 * i + 1] = c2 * b[0] - c0 * b[2];
-            o.Gx[3 * i + 2] = c0 * b[1] - c1 * b[0];
+            Gx[3 * i] = c1 * b[2] - c2 * b[1];
+            Gx[3 * i + 1] = c2 * b[0] - c0 * b[2];
+            Gx[3 * i + 2] = c0 * b[1] - c1 * b[0];
         }
     }
-    // S = G P G^T + R_k (upper triangle), R_k = N R N^T, N = [-Cc C_vc, [r]x (direct); 0, C_vc] (EKF.cpp:462-475)
+    // R_k = N R N^T (upper triangle), N = [-Cc C_vc, [r]x (direct); 0, C_vc] (EKF.cpp:462-472)
+    V N00[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            N00[i][j] = -(Cc[3 * i] * V(p.C_vc[j]) + Cc[3 * i + 1] * V(p.C_vc[3 + j]) + Cc[3 * i + 2] * V(p.C_vc[6 + j]));
+    }
+    V Sr[3][3] = {{V(0), -r[2], r[1]}, {r[2], V(0), -r[0]}, {-r[1], r[0], V(0)}};
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int j = i; j < 3; ++j) {
+            V s = N00[i][0] * nz.R[0] * N00[j][0] + N00[i][1] * nz.R[1] * N00[j][1] + N00[i][2] * nz.R[2] * N00[j][2];
+            if (DIRECT) s = s + (Sr[i][0] * nz.R[3] * Sr[j][0] + Sr[i][1] * nz.R[4] * Sr[j][1] + Sr[i][2] * nz.R[5] * Sr[j][2]);
+            Rk[rk_idx(i, j)] = s;
+            Rk[rk_idx(3 + i, 3 + j)] = V(p.C_vc[3 * i]) * nz.R[3] * V(p.C_vc[3 * j]) + V(p.C_vc[3 * i + 1]) * nz.R[4] * V(p.C_vc[3 * j + 1]) +
+                                       V(p.C_vc[3 * i + 2]) * nz.R[5] * V(p.C_vc[3 * j + 2]);
+        }
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            Rk[rk_idx(i, 3 + j)] = DIRECT ? Sr[i][0] * nz.R[3] * V(p.C_vc[3 * j]) + Sr[i][1] * nz.R[4] * V(p.C_vc[3 * j + 1]) +
+                                                Sr[i][2] * nz.R[5] * V(p.C_vc[3 * j + 2])
+                                          : V(0);
+    }
+}
+
+// `in` hands over, value by value (in.Frr(k), in.Frt(k), in.Ftt(k): the predicted covariance blocks (r,r), (r,th), (th,th), full 3x3
+// row-major; in.dy(k), in.Gx(k), in.Rk(k)): the device reads each from LDS where it is used, FactorIn holds plain values.
+template <class V>
+struct FactorIn {
+    V frr[9], frt[9], ftt[9], dy_[6], gx[9], rk[kRkWords];
+    __host__ __device__ V Frr(int k) const { return frr[k]; }
+    __host__ __device__ V Frt(int k) const { return frt[k]; }
+    __host__ __device__ V Ftt(int k) const { return ftt[k]; }
+    __host__ __device__ V dy(int k) const { return dy_[k]; }
+    __host__ __device__ V Gx(int k) const { return gx[k]; }
+    __host__ __device__ V Rk(int k) const { return rk[k]; }
+};
+template <class Q, bool DIRECT, class In>
+__host__ __device__ __forceinline__ void update_factor(const In& in, UpdU<typename Q::V>& o)
+{
+    using V = typename Q::V;
     V S[6][6];
-    {
-        V N00[3][3];
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                N00[i][j] = -(Cc[3 * i] * V(p.C_vc[j]) + Cc[3 * i + 1] * V(p.C_vc[3 + j]) + Cc[3 * i + 2] * V(p.C_vc[6 + j]));
-        }
-        V Sr[3][3] = {{V(0), -r[2], r[1]}, {r[2], V(0), -r[0]}, {-r[1], r[0], V(0)}};
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int j = i; j < 3; ++j) {
-                V s = N00[i][0] * nz.R[0] * N00[j][0] + N00[i][1] * nz.R[1] * N00[j][1] + N00[i][2] * nz.R[2] * N00[j][2];
-                if (DIRECT) s = s + (Sr[i][0] * nz.R[3] * Sr[j][0] + Sr[i][1] * nz.R[4] * Sr[j][1] + Sr[i][2] * nz.R[5] * Sr[j][2]);
-                S[i][j] = s;
-                S[3 + i][3 + j] = V(p.C_vc[3 * i]) * nz.R[3] * V(p.C_vc[3 * j]) + V(p.C_vc[3 * i + 1]) * nz.R[4] * V(p.C_vc[3 * j + 1]) +
-                                  V(p.C_vc[3 * i + 2]) * nz.R[5] * V(p.C_vc[3 * j + 2]);
-            }
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                S[i][3 + j] = DIRECT ? Sr[i][0] * nz.R[3] * V(p.C_vc[3 * j]) + Sr[i][1] * nz.R[4] * V(p.C_vc[3 * j + 1]) +
-                                           Sr[i][2] * nz.R[5] * V(p.C_vc[3 * j + 2])
-                                     : V(0);
-        }
-    }
     if (DIRECT) {
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                if (k >= i) { S[i][k] = S[i][k] + Frr[3 * i + k]; S[3 + i][3 + k] = S[3 + i][3 + k] + Ftt[3 * i + k]; }
-                S[i][3 + k] = S[i][3 + k] + Frt[3 * i + k];
+                if (k >= i) { S[i][k] = in.Rk(rk_idx(i, k)) + in.Frr(3 * i + k); S[3 + i][3 + k] = in.Rk(rk_idx(3 + i, 3 + k)) + in.Ftt(3 * i + k); }
+                S[i][3 + k] = in.Rk(rk_idx(i, 3 + k)) + in.Frt(3 * i + k);
             }
         }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) o.Gx[k] = V(0);
     } else {
+        V Gx[9], Frt[9], Ftt[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { Gx[k] = in.Gx(k); Frt[k] = in.Frt(k); Ftt[k] = in.Ftt(k); o.Gx[k] = Gx[k]; }
         V E[3][3];   // P_rt + Gx P_tt
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k) E[i][k] = Frt[3 * i + k] + (o.Gx[3 * i] * Ftt[k] + o.Gx[3 * i + 1] * Ftt[3 + k] + o.Gx[3 * i + 2] * Ftt[6 + k]);
+            for (int k = 0; k < 3; ++k) E[i][k] = Frt[3 * i + k] + (Gx[3 * i] * Ftt[k] + Gx[3 * i + 1] * Ftt[3 + k] + Gx[3 * i + 2] * Ftt[6 + k]);
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 if (k >= i) {
-                    S[i][k] = S[i][k] + Frr[3 * i + k] + (o.Gx[3 * i] * Frt[3 * k] + o.Gx[3 * i + 1] * Frt[3 * k + 1] + o.Gx[3 * i + 2] * Frt[3 * k + 2]) +
-                              (E[i][0] * o.Gx[3 * k] + E[i][1] * o.Gx[3 * k + 1] + E[i][2] * o.Gx[3 * k + 2]);
-                    S[3 + i][3 + k] = S[3 + i][3 + k] + Ftt[3 * i + k];
+                    S[i][k] = in.Rk(rk_idx(i, k)) + in.Frr(3 * i + k) + (Gx[3 * i] * Frt[3 * k] + Gx[3 * i + 1] * Frt[3 * k + 1] + Gx[3 * i + 2] * Frt[3 * k + 2]) +
+                              (E[i][0] * Gx[3 * k] + E[i][1] * Gx[3 * k + 1] + E[i][2] * Gx[3 * k + 2]);
+                    S[3 + i][3 + k] = in.Rk(rk_idx(3 + i, 3 + k)) + Ftt[3 * i + k];
                 }
-                S[i][3 + k] = S[i][3 + k] + E[i][k];
+                S[i][3 + k] = in.Rk(rk_idx(i, 3 + k)) + E[i][k];
             }
         }
     }
     // S = L D L^T (unit lower L); y' = L^-1 dy; yd = D^-1 y'
+    V dy[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dy[k] = in.dy(k);
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
         o.invd[c] = V(1) / S[c][c];
@@ -554,6 +615,21 @@ __host__ __device__ __forceinline__ void update_scalar(const DevParams<T>& p, co
     }
 #pragma unroll
     for (int m = 0; m < 6; ++m) o.yd[m] = dy[m] * o.invd[m];
+}
+
+// The three parts in one call (host check, and callers that have nothing to overlap).
+template <class Q, typename T, bool DIRECT, typename EmitObs>
+__host__ __device__ __forceinline__ void update_scalar(const DevParams<T>& p, const NoiseV<typename Q::V>& nz, const typename Q::V (&x)[16],
+                                                       const typename Q::V (&z)[7], const typename Q::V (&Frr)[9], const typename Q::V (&Frt)[9],
+                                                       const typename Q::V (&Ftt)[9], UpdU<typename Q::V>& o, EmitObs&& emit_obs)
+{
+    using V = typename Q::V;
+    FactorIn<V> in;
+    update_innovation<Q, T, DIRECT>(p, x, z, in.dy_, emit_obs);
+    update_noise<Q, T, DIRECT>(p, nz, x, in.gx, in.rk);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { in.frr[k] = Frr[k]; in.frt[k] = Frt[k]; in.ftt[k] = Ftt[k]; }
+    update_factor<Q, DIRECT>(in, o);
 }
 
 // --------------------------------------------------------- update, on quads
@@ -598,20 +674,23 @@ __host__ __device__ __forceinline__ void update_P(const G& g, typename Q::V (&Ln
         for (int m = 1; m < 6; ++m) s = s + v[b][m] * g.yd(m);
         dxo[b] = s;
     }
+    // Written as accumulations with the sign in the scaled factor (P += v_i (-v_k / d)): `acc + dpp_read(a) * b` is one
+    // v_fmac_f32 with the cross-lane read folded into its first operand; `acc - dpp_read(a) * b` would need the 3-operand form, which
+    // cannot take a DPP operand, so every read would become a move of its own and a register (+55 VGPRs, profiles/r02_tuning.md).
 #pragma unroll
     for (int m = 0; m < 6; ++m) {
-        V vs[5];
+        V nvs[5];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) vs[c] = v[c][m] * g.invd(m);
+        for (int c = 0; c < 5; ++c) nvs[c] = v[c][m] * (-g.invd(m));
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
-            Ln[QLE_QD0(b)] = Ln[QLE_QD0(b)] - v[b][m] * vs[b];
-            Ln[QLE_QD1(b)] = Ln[QLE_QD1(b)] - Q::rot2(v[b][m]) * vs[b];
+            Ln[QLE_QD0(b)] = Ln[QLE_QD0(b)] + v[b][m] * nvs[b];
+            Ln[QLE_QD1(b)] = Ln[QLE_QD1(b)] + Q::rot2(v[b][m]) * nvs[b];
 #pragma unroll
             for (int c = b + 1; c < 5; ++c) {
-                Ln[QLE_QO(b, c, 0)] = Ln[QLE_QO(b, c, 0)] - Q::template bc<0>(v[b][m]) * vs[c];
-                Ln[QLE_QO(b, c, 1)] = Ln[QLE_QO(b, c, 1)] - Q::template bc<1>(v[b][m]) * vs[c];
-                Ln[QLE_QO(b, c, 2)] = Ln[QLE_QO(b, c, 2)] - Q::template bc<2>(v[b][m]) * vs[c];
+                Ln[QLE_QO(b, c, 0)] = Ln[QLE_QO(b, c, 0)] + Q::template bc<0>(v[b][m]) * nvs[c];
+                Ln[QLE_QO(b, c, 1)] = Ln[QLE_QO(b, c, 1)] + Q::template bc<1>(v[b][m]) * nvs[c];
+                Ln[QLE_QO(b, c, 2)] = Ln[QLE_QO(b, c, 2)] + Q::template bc<2>(v[b][m]) * nvs[c];
             }
         }
     }

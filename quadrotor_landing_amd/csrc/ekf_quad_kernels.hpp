@@ -6,9 +6,11 @@
 //   quad role   (all four waves)  thread t is lane t%4 of the quad of filter t/4: lanes 0..2 load / store the ten
 //                                 16-byte quads 3m + j of the packed covariance (column j of every 3x3 block, sidx in
 //                                 ekf_device.hpp) and run the covariance algebra on them (quad::predict_P / update_P);
-//   scalar role (wave 0 only)     thread t < 64 owns filter t: loads x, u, z (and the per-filter parameters), runs
-//                                 the per-filter scalar arithmetic once (quad::predict_scalar / update_scalar /
-//                                 update_inject) and stores x.
+//   scalar role (waves 0, 1, 2)   thread t of wave w owns filter t % 64: wave 0 loads x, u, z (and the per-filter parameters), runs
+//                                 quad::predict_scalar, later update_factor and update_inject, and stores x; on ticks with tag
+//                                 poses waves 1 and 2 meanwhile compute the parts of the correction that need only the predicted
+//                                 nominal state -- the innovation (wave 1) and Gx, R_k (wave 2) -- so that the three dependent
+//                                 scalar chains run side by side instead of one after the other.
 //
 // The two roles talk through a per-filter LDS record (kLdsStride words): predict_scalar -> {A, Bm, Rt, C Qa C^T, Q diag}
 // -> predict_P -> {P_rr, P_rt, P_tt} -> update_scalar -> {L, D^-1, D^-1 L^-1 dy, Gx} -> update_P -> {dx} -> update_inject,
@@ -28,8 +30,9 @@ namespace qle {
 constexpr int kLdsU1 = 0;     // PredU (45 words); later UpdU (36 words)
 constexpr int kLdsFlag = 45;  // bit 0: filter initialised and in range, bit 1: it corrects on this tick
 constexpr int kLdsU2 = 46;    // P_rr, P_rt, P_tt (27 words); later dx (15 words)
-constexpr int kLdsPark = 73;  // the scalar role's x (16), tag record (8) and R diag (6) while the quads work
-constexpr int kLdsStride = 103;
+constexpr int kLdsPark = 73;  // wave 0's predicted x (16) while the quads work
+constexpr int kLdsPre = 89;   // from waves 1 and 2: dy (6), Gx (9), R_k upper triangle (21), reported observation (7)
+constexpr int kLdsStride = 133;
 
 // The quads' view of the scalar results: every value is fetched from the filter's LDS record where it is used.
 template <typename T>
@@ -47,6 +50,16 @@ struct LdsPredQ {
     __device__ __forceinline__ T qw() const { return rec[kLdsU1 + 36 + j]; }
     __device__ __forceinline__ T qab() const { return rec[kLdsU1 + 39 + j]; }
     __device__ __forceinline__ T qwb() const { return rec[kLdsU1 + 42 + j]; }
+};
+template <typename T>
+struct LdsFactorIn {
+    const T* rec;
+    __device__ __forceinline__ T Frr(int k) const { return rec[kLdsU2 + k]; }
+    __device__ __forceinline__ T Frt(int k) const { return rec[kLdsU2 + 9 + k]; }
+    __device__ __forceinline__ T Ftt(int k) const { return rec[kLdsU2 + 18 + k]; }
+    __device__ __forceinline__ T dy(int k) const { return rec[kLdsPre + k]; }
+    __device__ __forceinline__ T Gx(int k) const { return rec[kLdsPre + 6 + k]; }
+    __device__ __forceinline__ T Rk(int k) const { return rec[kLdsPre + 15 + k]; }
 };
 template <typename T, bool DIRECT>
 struct LdsUpdQ {
@@ -181,17 +194,58 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
                     for (int k = 0; k < 3; ++k) aux_accel[is * 3 + k] = accel[k];
                 }
                 if (!(STEP && corr)) store_rec<T, kSW, 0, kXW, NT>(st, is, x);
-                else {   // the scalar role's state waits in LDS while the quads work (keeps the quad phases' register count down)
+                else {   // the predicted nominal state waits in LDS while the quads work (keeps the quad phases' register count down)
 #pragma unroll
                     for (int k = 0; k < kXW; ++k) mine[kLdsPark + k] = x[k];
-#pragma unroll
-                    for (int k = 0; k < 7; ++k) mine[kLdsPark + kXW + k] = zr[k];
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) mine[kLdsPark + kXW + 8 + k] = nz.R[k];
                 }
             }
         }
         mine[kLdsFlag] = T((live ? 1 : 0) | (corr ? 2 : 0));
+    } else if (STEP && t < 3 * kTile) {
+        // waves 1 and 2, filter t % 64: what the correction needs of the predicted NOMINAL state only, side by side with wave 0
+        const int fs = t & (kTile - 1);
+        const int64_t js = tile * kTile + fs;
+        T* rec_s = lds + fs * kLdsStride;
+        if (js < B) {
+            T x[kXW], u[kUW], zr[kZW];
+            load_rec<T, kUW, 0, kUW, NT>(us, js, u);
+            load_rec<T, kSW, 0, kXW, NT>(st, js, x);
+            load_rec<T, kZW, 0, kZW, NT>(zs, js, zr);
+            quad::NoiseV<T> nz;
+            if (PFP) {
+                T fp[kFW];
+                load_rec<T, kFW, 0, kFW, NT>(pfp, js, fp);
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nz.ab_static[k] = fp[12 + k]; nz.wb_static[k] = fp[15 + k]; }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nz.R[k] = fp[18 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nz.ab_static[k] = p.ab_static[k]; nz.wb_static[k] = p.wb_static[k]; }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nz.R[k] = p.R[k];
+            }
+            if (!filter_uninitialised(x) && zr[7] != T(0)) {
+                quad::predict_nominal<SQ, T>(p, nz, x, u);
+                if (t < 2 * kTile) {
+                    const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+                    T dy[6];
+                    quad::update_innovation<SQ, T, DIRECT>(p, x, z, dy, [&](const T (&obs)[7]) {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) rec_s[kLdsPre + 36 + k] = obs[k];
+                    });
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) rec_s[kLdsPre + k] = dy[k];
+                } else {
+                    T Gx[9], Rk[quad::kRkWords];
+                    quad::update_noise<SQ, T, DIRECT>(p, nz, x, Gx, Rk);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) rec_s[kLdsPre + 6 + k] = Gx[k];
+#pragma unroll
+                    for (int k = 0; k < quad::kRkWords; ++k) rec_s[kLdsPre + 15 + k] = Rk[k];
+                }
+            }
+        }
     }
     __syncthreads();
 
@@ -224,23 +278,12 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
     // ---- scalar role: innovation, S = G P G^T + R_k = L D L^T
     const bool corr_s = scalar_wave && ((int)mine[kLdsFlag] & 2) != 0;
     if (corr_s) {
-        T x[kXW], Frr[9], Frt[9], Ftt[9];
-        quad::NoiseV<T> nz;
-#pragma unroll
-        for (int k = 0; k < kXW; ++k) x[k] = mine[kLdsPark + k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) nz.R[k] = mine[kLdsPark + kXW + 8 + k];
-#pragma unroll
-        for (int k = 0; k < 9; ++k) { Frr[k] = mine[kLdsU2 + k]; Frt[k] = mine[kLdsU2 + 9 + k]; Ftt[k] = mine[kLdsU2 + 18 + k]; }
-        const T z[7] = {mine[kLdsPark + kXW], mine[kLdsPark + kXW + 1], mine[kLdsPark + kXW + 2], mine[kLdsPark + kXW + 3],
-                        mine[kLdsPark + kXW + 4], mine[kLdsPark + kXW + 5], mine[kLdsPark + kXW + 6]};
         quad::UpdU<T> uu;
-        quad::update_scalar<SQ, T, DIRECT>(p, nz, x, z, Frr, Frt, Ftt, uu, [&](const T (&obs)[7]) {
-            if (aux_accel) {
+        quad::update_factor<SQ, DIRECT>(LdsFactorIn<T>{mine}, uu);
+        if (aux_accel) {
 #pragma unroll
-                for (int k = 0; k < 7; ++k) aux_obs[is * 7 + k] = obs[k];
-            }
-        });
+            for (int k = 0; k < 7; ++k) aux_obs[is * 7 + k] = mine[kLdsPre + 36 + k];
+        }
 #pragma unroll
         for (int k = 0; k < 15; ++k) mine[kLdsU1 + k] = uu.Lm[k];
 #pragma unroll
