@@ -291,10 +291,10 @@ def main():
     bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * ekf.algorithmic_bytes(1)
     wsz = 4 if args.dtype == "f32" else 8
     if mr_step:
-        # multirate correction tick per filter (lazy history, k_step_mr): read u6 + z8 + the entry the measurement
-        # belongs to (136) + the (step-1) stored IMU samples in between (8 words each); write the corrected entry (136)
-        # and the newest entry (144).  The reference-shaped eager scheme also rewrote the step-1 entries in between.
-        words = (6 + 8 + 136 + 8 * (mr_step - 1)) + (136 + 144)
+        # multirate correction tick per filter (k_step_mr, checkpointed history): read u6 + z8 + the checkpoint / anchor the replay
+        # starts from (136) + the stored IMU samples of the replayed ticks (8 words each, step + (k-1)/2 on average, k = 16);
+        # write the anchor (136), the state (136), its IMU sample (8) and the checkpoints passed on the way (136 x step / k)
+        words = (6 + 8 + 136 + 8 * (mr_step + 7)) + (136 + 136 + 8 + 136 * mr_step // 16)
         bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * words * wsz * B
     bad = ekf.count_nonfinite()
     # per-device error sums vs the generator's truth at the end of the resident sequence (cfg 5 reduction): the truth is the

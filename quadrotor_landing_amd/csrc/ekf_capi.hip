@@ -138,7 +138,6 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
         e = hipMemsetAsync(nr, 0, slot_bytes(h), h->stream);   // all-zero records = filters not initialised
         if (e != hipSuccess) { (void)hipFree(nr); return fail(QLE_ERR_HIP, "state setup: %s", hipGetErrorString(e)); }
         h->ring = nr;
-        h->C = 1;
     }
     if (mr && (!h->hist_first || Nc != h->mr_Nc)) {
         int32_t* hf = nullptr;
@@ -526,7 +525,7 @@ static int launch_step(qle_batch* h, const void* u, const void* z)
 
 
 // One filter_update tick has been launched.  Tick indices are 32-bit on the device
-// (last_corr, ring slot = tick % C); long before they could wrap, shift the origin by a
+// (last_corr, hist_first, history slots = tick modulo the ring sizes); long before they could wrap, shift the origin by a
 // multiple of the ring capacity so that slots and differences are unchanged.
 static int advance_tick(qle_batch* h)
 {

@@ -63,11 +63,8 @@ struct qle_batch {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     int64_t Bp = 0;        // batch padded to whole 64-filter tiles
-    // State storage: ring of C arrays of 144-word state records, slot = tick % C.  C = 1 for the
-    // single-rate filter (in place); C = max step delay + 1 for the multirate filter, where the
-    // ring is the history of EKF.hpp:62-64.  The state "now" is slot (tick-1) % C.
+    // The state: one array of 144-word records (x 16, packed P 120, 8 pad), updated in place.
     void* ring = nullptr;
-    int32_t C = 0;
     void* pfp = nullptr;   // [24 words] per-filter params, wave tiles
     bool pfp_on = false;
     bool aux = false;
@@ -140,14 +137,8 @@ template <> const DevParams<double>& dev<double>(const qle_batch* h) { return h-
 static inline dim3 grid_for(const qle_batch* h, int block) { return dim3((unsigned)((h->B + block - 1) / block)); }
 
 static inline size_t slot_bytes(const qle_batch* h) { return (size_t)kSW * (size_t)h->Bp * h->wsz; }
-static inline int32_t slot_of(const qle_batch* h, int64_t tick)
-{
-    int64_t s = tick % h->C;
-    return (int32_t)(s < 0 ? s + h->C : s);
-}
-// state after the last executed tick / state the next tick writes
-static inline void* state_cur(const qle_batch* h) { return (char*)h->ring + slot_bytes(h) * (size_t)slot_of(h, h->tick - 1); }
-static inline void* state_next(const qle_batch* h) { return (char*)h->ring + slot_bytes(h) * (size_t)slot_of(h, h->tick); }
+// the state: one record array, updated in place by every tick
+static inline void* state_cur(const qle_batch* h) { return h->ring; }
 
 #define BY_DTYPE(h, FN, ...) ((h)->dtype == QLE_F32 ? FN<float>(__VA_ARGS__) : FN<double>(__VA_ARGS__))
 

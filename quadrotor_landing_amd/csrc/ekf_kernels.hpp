@@ -36,8 +36,7 @@ constexpr int kTile = 64;   // filters per tile = wavefront size
 template <typename T> struct PredictWaves { static constexpr int value = sizeof(T) == 4 ? QLE_PREDICT_WAVES_F32 : 1; };
 constexpr int kXW = 16;     // state words
 constexpr int kPW = 120;    // packed covariance words
-constexpr int kUoff = kXW + kPW; // word offset of the stored IMU sample inside the state record
-constexpr int kSW = kXW + kPW + 8;  // state record: x, P, u(6) + 2 pad
+constexpr int kSW = kXW + kPW + 8;  // state record: x, P, 8 words of padding (36 / 72 KiB per tile)
 constexpr int kUW = 6;      // IMU words
 constexpr int kZW = 8;      // tag pose 7 words + mask word
 constexpr int kFW = 24;     // per-filter parameter words

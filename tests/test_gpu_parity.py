@@ -606,12 +606,13 @@ def test_multirate_replay_matches_reference_logic(cfg, dtype, T=60, loosen=1.0):
     ekf.close()
 
 
-def test_multirate_lazy_history_over_ring_wraps(dtype="f64"):
-    """The engine writes only the corrected and the newest history entry on a correction tick and recomputes the
-    entries in between when a later measurement belongs to one of them (k_step_mr).  Measurements on ~45 % of the
-    ticks with 0-300 ms of latency and no rate limit put most corrections into such a stale zone; 260 ticks cross
-    the 71-entry ring more than three times.  Every tick must still match the reference logic (fp64: the randomly
-    driven free run is too long for an fp32-vs-fp64 comparison tick by tick)."""
+def test_multirate_history_over_ring_wraps(dtype="f64"):
+    """The engine keeps the state in place, an IMU ring, a state checkpoint every 16 ticks and a per-filter anchor at the last
+    correction, and rebuilds the entry a measurement belongs to by replaying from the newest checkpoint or the anchor (k_step_mr).
+    Measurements on ~45 % of the ticks with 0-300 ms of latency and no rate limit put corrections at every offset between
+    checkpoints, before and after the previous correction's entry; 260 ticks cross the 64-slot IMU ring four times and every
+    checkpoint slot several times.  Every tick must still match the reference logic (fp64: the randomly driven free run is too
+    long for an fp32-vs-fp64 comparison tick by tick)."""
     test_multirate_replay_matches_reference_logic(
         dict(dynamic_meas_delay=1, measurement_delay=0.150, measurement_delay_max=0.350, dyn_measurement_delay_offset=0.085,
              limit_measurement_freq=0, **HW_TAGS), dtype, T=260, loosen=100.0)   # free run: rounding accumulates with the tick count
@@ -854,7 +855,7 @@ def test_twin_interface_reproduces_twin_goldens():
 
 
 def test_tick_origin_shift_is_invisible(monkeypatch):
-    """Tick indices are 32-bit on the device (last_corr, hist_first, ring slot = tick % C); the host shifts the
+    """Tick indices are 32-bit on the device (last_corr, hist_first, history slots = tick modulo the ring sizes); the host shifts the
     origin long before they could wrap.  With the threshold lowered to 48 ticks the gating and multirate parity
     tests cross several shifts and must still match the oracle tick for tick."""
     monkeypatch.setenv("QLE_TICK_REBASE", "48")
