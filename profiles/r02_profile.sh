@@ -1,8 +1,9 @@
 #!/bin/bash
 # Round-2 evidence, regenerated in one go on the GPU box from the committed head:
 #     gpurun --timeout 1150 -- "bash profiles/r02_profile.sh $(git rev-parse --short HEAD)"
-# bench lines of every workload, rocprofv3 kernel stats of the headline command, FETCH_SIZE / WRITE_SIZE passes (separate --pmc
-# runs, --kernel-trace only) at 65 536 filters, at 2 097 152 filters and for cfg 2, SQ / TCC passes at 65 536 and 262 144 filters.
+# FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs, --kernel-trace only) at 65 536 filters, at 2 097 152 filters and for cfg 2
+# (-> traffic.json, read by the bench lines that follow), bench lines of every workload, rocprofv3 kernel stats of the headline
+# command, SQ / TCC passes at 65 536 and 262 144 filters, the batch sweep, the accuracy table.
 # Raw CSVs stay under gpurun_out/ (scratch); the summaries go to profiles/ via gpurun_out/r2/profiles_out/ (copied back by hand).
 export QLE_HEAD_SHA=${1:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -11,6 +12,24 @@ R=gpurun_out/r2/prof
 rm -rf $O $R; mkdir -p $O $R
 py=python3
 step() { echo "== $*"; }
+
+step HBM traffic counters
+pmc() {  # tag counter args...
+  tag=$1; ctr=$2; shift 2
+  rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $R/pmc_$tag -o p -- $py bench.py --no-cpu-baseline --no-extras "$@" > $R/pmc_$tag.log 2>&1
+  $py profiles/summarize.py $R/pmc_$tag $O/r02_pmc_$tag.md "--pmc $ctr -- bench.py $*"
+}
+pmc fetch_b65536 FETCH_SIZE --steps 280 --kernel-steps 200
+pmc write_b65536 WRITE_SIZE --steps 280 --kernel-steps 200
+$py profiles/summarize.py --traffic $R/pmc_fetch_b65536 $R/pmc_write_b65536 cfg3:65536:f32:predict 'k_predict<float, false, 2, false>' $O/traffic.json
+pmc fetch_b2097152 FETCH_SIZE --batch-per-gpu 2097152 --steps 56 --warmup 14 --kernel-steps 40
+pmc write_b2097152 WRITE_SIZE --batch-per-gpu 2097152 --steps 56 --warmup 14 --kernel-steps 40
+$py profiles/summarize.py --traffic $R/pmc_fetch_b2097152 $R/pmc_write_b2097152 cfg3:2097152:f32:predict 'k_predict<float, false, 3, false>' $O/traffic.json
+pmc fetch_cfg2 FETCH_SIZE --workload cfg2 --steps 200 --kernel-steps 200
+pmc write_cfg2 WRITE_SIZE --workload cfg2 --steps 200 --kernel-steps 200
+$py profiles/summarize.py --traffic $R/pmc_fetch_cfg2 $R/pmc_write_cfg2 cfg2:4096:f64:step 'kw_tick<double' $O/traffic.json
+
+cp $O/traffic.json profiles/traffic.json   # the bench lines below read it (roofline.traffic)
 
 step bench lines
 timeout -k 10 600 $py bench.py > $O/r02_bench.json 2> $R/bench.err || tail -5 $R/bench.err
@@ -31,22 +50,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats_mr -o s -- $py 
 $py profiles/summarize.py $R/stats_mr $O/r02_kernel_stats_multirate.md "bench.py --workload cfg3mr --steps 1400"
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/stats_f64 -o s -- $py bench.py --dtype f64 --no-cpu-baseline --no-extras --steps 1400 > $R/stats_f64.log 2>&1
 $py profiles/summarize.py $R/stats_f64 $O/r02_kernel_stats_f64.md "bench.py --dtype f64 --steps 1400 (cfg3 schedule, 65 536 fp64 filters)"
-
-step HBM traffic counters
-pmc() {  # tag counter args...
-  tag=$1; ctr=$2; shift 2
-  rocprofv3 --kernel-trace --output-format csv --pmc $ctr -d $R/pmc_$tag -o p -- $py bench.py --no-cpu-baseline --no-extras "$@" > $R/pmc_$tag.log 2>&1
-  $py profiles/summarize.py $R/pmc_$tag $O/r02_pmc_$tag.md "--pmc $ctr -- bench.py $*"
-}
-pmc fetch_b65536 FETCH_SIZE --steps 280 --kernel-steps 200
-pmc write_b65536 WRITE_SIZE --steps 280 --kernel-steps 200
-$py profiles/summarize.py --traffic $R/pmc_fetch_b65536 $R/pmc_write_b65536 cfg3:65536:f32:predict 'k_predict<float, false, 2, false>' $O/traffic.json
-pmc fetch_b2097152 FETCH_SIZE --batch-per-gpu 2097152 --steps 56 --warmup 14 --kernel-steps 40
-pmc write_b2097152 WRITE_SIZE --batch-per-gpu 2097152 --steps 56 --warmup 14 --kernel-steps 40
-$py profiles/summarize.py --traffic $R/pmc_fetch_b2097152 $R/pmc_write_b2097152 cfg3:2097152:f32:predict 'k_predict<float, false, 3, false>' $O/traffic.json
-pmc fetch_cfg2 FETCH_SIZE --workload cfg2 --steps 200 --kernel-steps 200
-pmc write_cfg2 WRITE_SIZE --workload cfg2 --steps 200 --kernel-steps 200
-$py profiles/summarize.py --traffic $R/pmc_fetch_cfg2 $R/pmc_write_cfg2 cfg2:4096:f64:step 'kw_tick<double' $O/traffic.json
 
 step SQ and TCC counters, 65536 vs 262144 filters
 for B in 65536 262144; do
