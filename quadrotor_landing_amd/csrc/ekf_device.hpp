@@ -87,6 +87,23 @@ __host__ __device__ constexpr int word_block_row(int w)
     const int pos = 4 * ((w / 4) / 3) + w % 4;
     return pos < 14 ? 0 : pos < 25 ? 1 : pos < 33 ? 2 : pos < 38 ? 3 : 4;
 }
+// Inverse of sidx: the element (row <= col) stored in word w.
+__host__ __device__ constexpr int word_lane(int w) { return (w / 4) % 3; }
+__host__ __device__ constexpr int word_pos(int w) { return 4 * ((w / 4) / 3) + w % 4; }
+__host__ __device__ constexpr int word_row(int w)
+{
+    const int l = word_lane(w), b = word_block_row(w), off = word_pos(w) - quad_group_base(b);
+    if (off == 0) return 3 * b + l;
+    if (off == 1) return 3 * b + (l == 2 ? 1 : 0);              // lane 0: (0,2), lane 1: (0,1), lane 2: (1,2)
+    return 3 * b + (off - 2) % 3;
+}
+__host__ __device__ constexpr int word_col(int w)
+{
+    const int l = word_lane(w), b = word_block_row(w), off = word_pos(w) - quad_group_base(b);
+    if (off == 0) return 3 * b + l;
+    if (off == 1) return 3 * b + (l == 1 ? 1 : 2);
+    return 3 * (b + 1 + (off - 2) / 3) + l;
+}
 // First word (a multiple of vw) from which on every stored element belongs to block-row >= b: the quads from
 // there to the end are final once the levelled predict has finished block-row b.
 __host__ __device__ constexpr int level_first_word(int b, int vw)
