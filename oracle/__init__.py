@@ -113,7 +113,8 @@ def quad_run_batch(p, x, P, u, z=None, mask=None, dtype="f64"):
 
 def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True, n_threads=0):
     """The engine's own per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_device.hpp) compiled for the CPU:
-    same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product."""
+    same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product.
+    levels: True = levelled predict + sequential update, False = in-place predict, "fused" = the fused tick (ekf_fused.hpp)."""
     _slib = _structured_lib()
     n = p.num_states
     x = np.array(x, dtype=np.float64, order="C").reshape(-1, 16)
@@ -126,7 +127,7 @@ def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True
         z = np.ascontiguousarray(z, dtype=np.float64).reshape(T, B, 7)
         mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(T, B)
         zp = _p(z); mp = mask.ctypes.data_as(C.POINTER(C.c_uint8))
-    _slib.orc_structured_run_batch(C.byref(p), B, T, _p(x), _p(P), _p(u), zp, mp, 0 if dtype == "f32" else 1, int(bool(levels)), int(n_threads))
+    _slib.orc_structured_run_batch(C.byref(p), B, T, _p(x), _p(P), _p(u), zp, mp, 0 if dtype == "f32" else 1, 2 if levels == "fused" else int(bool(levels)), int(n_threads))
     return x, P.reshape(B, n, n)
 
 

@@ -18,6 +18,7 @@
 
 #include "../quadrotor_landing_amd/csrc/ekf_device.hpp"
 #include "../quadrotor_landing_amd/csrc/ekf_quad.hpp"
+#include "../quadrotor_landing_amd/csrc/ekf_fused.hpp"
 #include "ekf_oracle.h"
 
 using namespace qle;
@@ -63,6 +64,24 @@ static int64_t run_batch_t(const orc_params* p, int64_t B, int64_t Tn, double* x
         for (int64_t t = 0; t < Tn; ++t) {
             const double* ut = u + (t * B + i) * 6;
             const T uu[6] = {(T)ut[0], (T)ut[1], (T)ut[2], (T)ut[3], (T)ut[4], (T)ut[5]};
+            if (levels == 2) {   // the whole tick as one schedule (ekf_fused.hpp), what k_step runs
+                const bool corr = mask && mask[t * B + i];
+                T zz[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};
+                if (corr) {
+                    const double* zt = z + (t * B + i) * 7;
+                    for (int k = 0; k < 7; ++k) zz[k] = (T)zt[k];
+                }
+                int groups = 0;
+                auto none3 = [](const T (&)[3]) {};
+                auto none7 = [](const T (&)[7]) {};
+                auto storex = []() {};
+                auto storeq = [&](int q4, const T* w4) { std::memcpy(&Pn[4 * q4], w4, 4 * sizeof(T)); ++groups; };
+                if (p->direct_orien_method) ekf_step_fused<T, true>(dp, nz, xs, Pp, uu, zz, corr, true, none3, none7, storex, storeq);
+                else ekf_step_fused<T, false>(dp, nz, xs, Pp, uu, zz, corr, true, none3, none7, storex, storeq);
+                if (groups != 30) xs[0] = (T)NAN;   // every 4-word group must be handed out exactly once
+                std::memcpy(Pp, Pn, sizeof(Pp));
+                continue;
+            }
             if (levels) {
                 ekf_predict_levels<T>(dp, nz, xs, Pp, uu, acc, Pn, [](int) {});
                 std::memcpy(Pp, Pn, sizeof(Pp));
@@ -194,7 +213,8 @@ int64_t orc_quad_run_batch(const orc_params* p, int64_t B, int64_t T, double* x,
     return dtype == 0 ? quad_run_batch_t<float>(p, B, T, x, P, u, z, mask) : quad_run_batch_t<double>(p, B, T, x, P, u, z, mask);
 }
 // Same contract as orc_run_batch (ekf_oracle.h).  dtype 0 = fp32 arithmetic, 1 = fp64.
-// levels != 0 uses the levelled predict (the one k_predict/k_step run), 0 the in-place congruences.
+// levels: 1 the levelled predict (the one k_predict runs) + sequential update, 0 the in-place congruences + sequential update,
+// 2 the fused tick of k_step (ekf_fused.hpp).
 int64_t orc_structured_run_batch(const orc_params* p, int64_t B, int64_t T, double* x, double* P, const double* u, const double* z,
                                  const uint8_t* mask, int dtype, int levels, int n_threads)
 {

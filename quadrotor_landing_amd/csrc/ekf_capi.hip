@@ -245,7 +245,6 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // poses, 2: predict-only ticks, 0: never).
     h->quad = batch <= 16384 ? 1 : 0;
     if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
-    if (const char* s = std::getenv("QLE_STEP_BATCH")) h->step_batch = std::atoi(s) != 0;
     // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
     // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16
     // -> predict tick 11.7 / 10.9 / 10.4 us, whole schedule 16.1 / 15.1 / 15.1 us per tick; 16 ships (history 0.6 GB).

@@ -206,30 +206,36 @@ __device__ __forceinline__ void quat_to_rot(const T (&q)[4], T (&C)[9])
 }
 
 // ------------------------------------------------------------------ predict
-// prediction_step, EKF.cpp:346-415.  x and P are updated in place; accel is
-// pose_accel (EKF.cpp:362).
+// The parts of prediction_step (EKF.cpp:346-415) that do not touch the covariance: see PredictCtx below.
 template <typename T>
-__device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
-                                            const T (&u)[6], T (&accel)[3])
+struct PredictCtx {
+    T a[3], dw[3];   // bias-corrected specific force, rotation increment dT (w - wb)
+    T C[9];          // rotation matrix of the OLD attitude (EKF.cpp:359)
+    T X[3][6];       // [A | Bm], A = -dT C [a]x (EKF.cpp:381), Bm = -dT C with est_bias (EKF.cpp:399)
+    T Rt[3][3];      // F[th,th], EKF.cpp:383-395
+    T dT, dTw;
+};
+// Nominal state, EKF.cpp:356-371: x is advanced in place, accel = pose_accel (EKF.cpp:362).
+template <typename T>
+__device__ __forceinline__ void predict_nominal(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], const T (&u)[6], T (&accel)[3],
+                                                PredictCtx<T>& c)
 {
     const T dT = p.dT;
-    T a[3], w[3];
+    c.dT = dT; c.dTw = p.dTw;
+    T w[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        a[i] = u[i] - x[10 + i] - nz.ab_static[i];      // EKF.cpp:357
-        w[i] = u[3 + i] - x[13 + i] - nz.wb_static[i];  // EKF.cpp:358
+        c.a[i] = u[i] - x[10 + i] - nz.ab_static[i];
+        w[i] = u[3 + i] - x[13 + i] - nz.wb_static[i];
     }
     T q[4] = {x[6], x[7], x[8], x[9]};
-    T C[9];
-    quat_to_rot(q, C);                                  // EKF.cpp:359
+    quat_to_rot(q, c.C);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-        accel[i] = (C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]) + p.g[i];  // EKF.cpp:362
-
-    // nominal state, EKF.cpp:365-371
-    T dw[3] = {dT * w[0], dT * w[1], dT * w[2]};
+    for (int i = 0; i < 3; ++i) accel[i] = (c.C[3 * i] * c.a[0] + c.C[3 * i + 1] * c.a[1] + c.C[3 * i + 2] * c.a[2]) + p.g[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) c.dw[i] = dT * w[i];
     T qe[4], qn[4];
-    quat_exp(dw, qe);
+    quat_exp(c.dw, qe);
     quat_mul(q, qe, qn);
     quat_norm(qn);
 #pragma unroll
@@ -238,41 +244,53 @@ __device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T
         x[3 + i] += dT * accel[i];
     }
     x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+}
 
-    // X = [A | Bm], A = -dT C [a]x (EKF.cpp:381), Bm = -dT C with est_bias (EKF.cpp:399)
-    T X[3][6];
-    const T mdT = -dT, mdTb = -dT * p.bias_on;
+// The blocks of F that are not identity: X = [A | Bm] and Rt.
+template <typename T>
+__device__ __forceinline__ void predict_jacobians(const DevParams<T>& p, PredictCtx<T>& c)
+{
+    const T mdT = -c.dT, mdTb = -c.dT * p.bias_on;
+    const T (&a)[3] = c.a;
+    const T (&dw)[3] = c.dw;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        T c0 = C[3 * i], c1 = C[3 * i + 1], c2 = C[3 * i + 2];
-        X[i][0] = mdT * (c1 * a[2] - c2 * a[1]);
-        X[i][1] = mdT * (c2 * a[0] - c0 * a[2]);
-        X[i][2] = mdT * (c0 * a[1] - c1 * a[0]);
-        X[i][3] = mdTb * c0; X[i][4] = mdTb * c1; X[i][5] = mdTb * c2;
+        T c0 = c.C[3 * i], c1 = c.C[3 * i + 1], c2 = c.C[3 * i + 2];
+        c.X[i][0] = mdT * (c1 * a[2] - c2 * a[1]);
+        c.X[i][1] = mdT * (c2 * a[0] - c0 * a[2]);
+        c.X[i][2] = mdT * (c0 * a[1] - c1 * a[0]);
+        c.X[i][3] = mdTb * c0; c.X[i][4] = mdTb * c1; c.X[i][5] = mdTb * c2;
     }
-    // Rt = F[th,th], EKF.cpp:383-395: I - [dw]x below small_ang_tol, else AngleAxis(-|dw|, dw/|dw|)
-    T Rt[3][3];
-    {
-        T ang = t_sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
-        bool small = ang < p.small_ang_tol;
-        T inv = T(1) / (small ? T(1) : ang);
-        T ax[3] = {dw[0] * inv, dw[1] * inv, dw[2] * inv};
-        T s, c;
-        t_sincos(-ang, &s, &c);
-        T sa[3] = {s * ax[0], s * ax[1], s * ax[2]};
-        T ca[3] = {(T(1) - c) * ax[0], (T(1) - c) * ax[1], (T(1) - c) * ax[2]};
-        T t01 = ca[0] * ax[1], t02 = ca[0] * ax[2], t12 = ca[1] * ax[2];
-        Rt[0][0] = small ? T(1) : ca[0] * ax[0] + c;
-        Rt[1][1] = small ? T(1) : ca[1] * ax[1] + c;
-        Rt[2][2] = small ? T(1) : ca[2] * ax[2] + c;
-        Rt[0][1] = small ? dw[2] : t01 - sa[2];
-        Rt[1][0] = small ? -dw[2] : t01 + sa[2];
-        Rt[0][2] = small ? -dw[1] : t02 + sa[1];
-        Rt[2][0] = small ? dw[1] : t02 - sa[1];
-        Rt[1][2] = small ? dw[0] : t12 - sa[0];
-        Rt[2][1] = small ? -dw[0] : t12 + sa[0];
-    }
+    T (&Rt)[3][3] = c.Rt;
+    T ang = t_sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
+    bool small = ang < p.small_ang_tol;
+    T inv = T(1) / (small ? T(1) : ang);
+    T ax[3] = {dw[0] * inv, dw[1] * inv, dw[2] * inv};
+    T sn, cs;
+    t_sincos(-ang, &sn, &cs);
+    T sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
+    T ca[3] = {(T(1) - cs) * ax[0], (T(1) - cs) * ax[1], (T(1) - cs) * ax[2]};
+    T t01 = ca[0] * ax[1], t02 = ca[0] * ax[2], t12 = ca[1] * ax[2];
+    Rt[0][0] = small ? T(1) : ca[0] * ax[0] + cs;
+    Rt[1][1] = small ? T(1) : ca[1] * ax[1] + cs;
+    Rt[2][2] = small ? T(1) : ca[2] * ax[2] + cs;
+    Rt[0][1] = small ? dw[2] : t01 - sa[2];
+    Rt[1][0] = small ? -dw[2] : t01 + sa[2];
+    Rt[0][2] = small ? -dw[1] : t02 + sa[1];
+    Rt[2][0] = small ? dw[1] : t02 - sa[1];
+    Rt[1][2] = small ? dw[0] : t12 - sa[0];
+    Rt[2][1] = small ? -dw[0] : t12 + sa[0];
+}
 
+// The covariance part of prediction_step, in place: P <- L3 (L2 (L1 P L1^T) L2^T) L3^T + W Q W^T as three symmetric congruences on the
+// packed upper triangle.
+template <typename T>
+__device__ __forceinline__ void predict_cov_inplace(const PredictCtx<T>& ctx, const Noise<T>& nz, T (&P)[120])
+{
+    const T dT = ctx.dT, dTw = ctx.dTw;
+    const T (&X)[3][6] = ctx.X;
+    const T (&Rt)[3][3] = ctx.Rt;
+    const T (&C)[9] = ctx.C;
     // ---- congruence 1: r <- r + dT v -------------------------------------
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -354,7 +372,6 @@ __device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T
     }
 
     // ---- congruence 3: th <- Rt th - dTw wb ------------------------------
-    const T dTw = p.dTw;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {  // rows r,v: P_k,th <- P_k,th Rt^T - dTw P_k,wb
         T o0 = QLE_PS(i, 6), o1 = QLE_PS(i, 7), o2 = QLE_PS(i, 8);
@@ -413,79 +430,32 @@ __device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T
     }
 }
 
+// prediction_step, EKF.cpp:346-415.  x and P are updated in place; accel is pose_accel (EKF.cpp:362).
+template <typename T>
+__device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
+                                            const T (&u)[6], T (&accel)[3])
+{
+    PredictCtx<T> c;
+    predict_nominal<T>(p, nz, x, u, accel, c);
+    predict_jacobians<T>(p, c);
+    predict_cov_inplace<T>(c, nz, P);
+}
+
 // ------------------------------------------------- predict, levelled variant
 // Same arithmetic as ekf_predict, organised for a memory-bound single wave per SIMD: the new
-// covariance Pn is computed block-row by block-row from the OLD P, bottom-up
+// covariance Pn is computed block-row by block-row from the OLD P
 //   level 0: rows ab, wb    (need old rows ab, wb)
 //   level 1: rows th        (need old rows th, ab, wb)
 //   level 2: rows v         (need old rows v, th, ab, wb)
 //   level 3: rows r         (need old rows r, v)
-// and `done(level)` is called after each level so the caller can issue that level's stores while
-// the loads of the rows above are still in flight (the caller issues the loads bottom-up too).
-// F = L3 L2 L1 as in ekf_predict; the formulas below are the composition written out per block.
-template <typename T, typename Done>
-__device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], const T (&P)[120],
-                                                   const T (&u)[6], T (&accel)[3], T (&Pn)[120], Done done)
-{
+// F = L3 L2 L1 as in ekf_predict; the formulas below are the composition written out per block.  The levels read only the old
+// covariance, so a caller may run them in any order: ekf_predict_levels goes bottom-up (stores of a level overlap the loads of the
+// rows above), the fused tick (ekf_fused.hpp) takes the rows the innovation covariance needs first.
 #define QLE_PN(i, j) Pn[::qle::sidx((i), (j))]
-    const T dT = p.dT, dTw = p.dTw;
-    T a[3], w[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        a[i] = u[i] - x[10 + i] - nz.ab_static[i];
-        w[i] = u[3 + i] - x[13 + i] - nz.wb_static[i];
-    }
-    T q[4] = {x[6], x[7], x[8], x[9]};
-    T C[9];
-    quat_to_rot(q, C);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) accel[i] = (C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]) + p.g[i];
-    T dw[3] = {dT * w[0], dT * w[1], dT * w[2]};
-    T qe[4], qn[4];
-    quat_exp(dw, qe);
-    quat_mul(q, qe, qn);
-    quat_norm(qn);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        x[i] += dT * x[3 + i];
-        x[3 + i] += dT * accel[i];
-    }
-    x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
-    done(-1);  // x is final
-
-    T X[3][6];
-    const T mdT = -dT, mdTb = -dT * p.bias_on;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        T c0 = C[3 * i], c1 = C[3 * i + 1], c2 = C[3 * i + 2];
-        X[i][0] = mdT * (c1 * a[2] - c2 * a[1]);
-        X[i][1] = mdT * (c2 * a[0] - c0 * a[2]);
-        X[i][2] = mdT * (c0 * a[1] - c1 * a[0]);
-        X[i][3] = mdTb * c0; X[i][4] = mdTb * c1; X[i][5] = mdTb * c2;
-    }
-    T Rt[3][3];
-    {
-        T ang = t_sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
-        bool small = ang < p.small_ang_tol;
-        T inv = T(1) / (small ? T(1) : ang);
-        T ax[3] = {dw[0] * inv, dw[1] * inv, dw[2] * inv};
-        T sn, cs;
-        t_sincos(-ang, &sn, &cs);
-        T sa[3] = {sn * ax[0], sn * ax[1], sn * ax[2]};
-        T ca[3] = {(T(1) - cs) * ax[0], (T(1) - cs) * ax[1], (T(1) - cs) * ax[2]};
-        T t01 = ca[0] * ax[1], t02 = ca[0] * ax[2], t12 = ca[1] * ax[2];
-        Rt[0][0] = small ? T(1) : ca[0] * ax[0] + cs;
-        Rt[1][1] = small ? T(1) : ca[1] * ax[1] + cs;
-        Rt[2][2] = small ? T(1) : ca[2] * ax[2] + cs;
-        Rt[0][1] = small ? dw[2] : t01 - sa[2];
-        Rt[1][0] = small ? -dw[2] : t01 + sa[2];
-        Rt[0][2] = small ? -dw[1] : t02 + sa[1];
-        Rt[2][0] = small ? dw[1] : t02 - sa[1];
-        Rt[1][2] = small ? dw[0] : t12 - sa[0];
-        Rt[2][1] = small ? -dw[0] : t12 + sa[0];
-    }
-
-    // ---- level 0: rows ab (9..11), wb (12..14) ----------------------------
+// level 0: rows ab (9..11), wb (12..14)
+template <typename T>
+__device__ __forceinline__ void predict_level0(const Noise<T>& nz, const T (&P)[120], T (&Pn)[120])
+{
 #pragma unroll
     for (int i = 9; i < 15; ++i) {
 #pragma unroll
@@ -496,92 +466,120 @@ __device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const 
         QLE_PN(9 + i, 9 + i) += nz.Q[6 + i];
         QLE_PN(12 + i, 12 + i) += nz.Q[9 + i];
     }
-    done(0);
-
-    // ---- level 1: rows th (6..8) -----------------------------------------
-    {
-        T Mtt[3][3];
+}
+// level 1: rows th (6..8)
+template <typename T>
+__device__ __forceinline__ void predict_level1(const PredictCtx<T>& c, const Noise<T>& nz, const T (&P)[120], T (&Pn)[120])
+{
+    const T (&Rt)[3][3] = c.Rt;
+    const T dTw = c.dTw;
+    T Mtt[3][3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                // th,wb and th,ab: Rt O_t* - dTw O_w*
-                QLE_PN(6 + i, 12 + c) = (Rt[i][0] * QLE_PS(6, 12 + c) + Rt[i][1] * QLE_PS(7, 12 + c) + Rt[i][2] * QLE_PS(8, 12 + c)) - dTw * QLE_PS(12 + i, 12 + c);
-                QLE_PN(6 + i, 9 + c) = (Rt[i][0] * QLE_PS(6, 9 + c) + Rt[i][1] * QLE_PS(7, 9 + c) + Rt[i][2] * QLE_PS(8, 9 + c)) - dTw * QLE_PS(12 + i, 9 + c);
-                Mtt[i][c] = (Rt[i][0] * QLE_PS(6, 6 + c) + Rt[i][1] * QLE_PS(7, 6 + c) + Rt[i][2] * QLE_PS(8, 6 + c)) - dTw * QLE_PS(12 + i, 6 + c);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-#pragma unroll
-            for (int k = i; k < 3; ++k)
-                QLE_PN(6 + i, 6 + k) = (Mtt[i][0] * Rt[k][0] + Mtt[i][1] * Rt[k][1] + Mtt[i][2] * Rt[k][2]) - dTw * QLE_PN(6 + i, 12 + k) +
-                                       ((i == k) ? nz.Q[3 + i] : T(0));
+        for (int cc = 0; cc < 3; ++cc) {
+            // th,wb and th,ab: Rt O_t* - dTw O_w*
+            QLE_PN(6 + i, 12 + cc) = (Rt[i][0] * QLE_PS(6, 12 + cc) + Rt[i][1] * QLE_PS(7, 12 + cc) + Rt[i][2] * QLE_PS(8, 12 + cc)) - dTw * QLE_PS(12 + i, 12 + cc);
+            QLE_PN(6 + i, 9 + cc) = (Rt[i][0] * QLE_PS(6, 9 + cc) + Rt[i][1] * QLE_PS(7, 9 + cc) + Rt[i][2] * QLE_PS(8, 9 + cc)) - dTw * QLE_PS(12 + i, 9 + cc);
+            Mtt[i][cc] = (Rt[i][0] * QLE_PS(6, 6 + cc) + Rt[i][1] * QLE_PS(7, 6 + cc) + Rt[i][2] * QLE_PS(8, 6 + cc)) - dTw * QLE_PS(12 + i, 6 + cc);
         }
     }
-    done(1);
-
-    // ---- level 2: rows v (3..5) --------------------------------------------
-    {
-        T Mv[3][9];  // M_v,[th ab wb] = O_v* + X O_[th ab],*
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int c = 0; c < 9; ++c) {
-                T acc = QLE_PS(3 + i, 6 + c);
+        for (int k = i; k < 3; ++k)
+            QLE_PN(6 + i, 6 + k) = (Mtt[i][0] * Rt[k][0] + Mtt[i][1] * Rt[k][1] + Mtt[i][2] * Rt[k][2]) - dTw * QLE_PN(6 + i, 12 + k) +
+                                   ((i == k) ? nz.Q[3 + i] : T(0));
+    }
+}
+// level 2: rows v (3..5)
+template <typename T>
+__device__ __forceinline__ void predict_level2(const PredictCtx<T>& c, const Noise<T>& nz, const T (&P)[120], T (&Pn)[120])
+{
+    const T (&Rt)[3][3] = c.Rt;
+    const T (&X)[3][6] = c.X;
+    const T (&C)[9] = c.C;
+    const T dTw = c.dTw;
+    T Mv[3][9];  // M_v,[th ab wb] = O_v* + X O_[th ab],*
 #pragma unroll
-                for (int m = 0; m < 6; ++m) acc += X[i][m] * QLE_PS(6 + m, 6 + c);
-                Mv[i][c] = acc;
-            }
-        }
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int cc = 0; cc < 9; ++cc) {
+            T acc = QLE_PS(3 + i, 6 + cc);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                QLE_PN(3 + i, 12 + c) = Mv[i][6 + c];
-                QLE_PN(3 + i, 9 + c) = Mv[i][3 + c];
-                QLE_PN(3 + i, 6 + c) = (Mv[i][0] * Rt[c][0] + Mv[i][1] * Rt[c][1] + Mv[i][2] * Rt[c][2]) - dTw * Mv[i][6 + c];
-            }
-#pragma unroll
-            for (int k = i; k < 3; ++k) {
-                T acc = QLE_PS(3 + i, 3 + k);
-#pragma unroll
-                for (int m = 0; m < 6; ++m) acc += X[i][m] * QLE_PS(3 + k, 6 + m);
-#pragma unroll
-                for (int m = 0; m < 6; ++m) acc += Mv[i][m] * X[k][m];
-                acc += C[3 * i] * nz.Q[0] * C[3 * k] + C[3 * i + 1] * nz.Q[1] * C[3 * k + 1] + C[3 * i + 2] * nz.Q[2] * C[3 * k + 2];
-                QLE_PN(3 + i, 3 + k) = acc;
-            }
+            for (int m = 0; m < 6; ++m) acc += X[i][m] * QLE_PS(6 + m, 6 + cc);
+            Mv[i][cc] = acc;
         }
     }
-    done(2);
-
-    // ---- level 3: rows r (0..2) --------------------------------------------
-    {
-        T M1[3][12];  // M1_r,[v th ab wb] = O_r* + dT O_v*
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 3; ++i) {
 #pragma unroll
-            for (int c = 0; c < 12; ++c) M1[i][c] = QLE_PS(i, 3 + c) + dT * QLE_PS(3 + i, 3 + c);
+        for (int cc = 0; cc < 3; ++cc) {
+            QLE_PN(3 + i, 12 + cc) = Mv[i][6 + cc];
+            QLE_PN(3 + i, 9 + cc) = Mv[i][3 + cc];
+            QLE_PN(3 + i, 6 + cc) = (Mv[i][0] * Rt[cc][0] + Mv[i][1] * Rt[cc][1] + Mv[i][2] * Rt[cc][2]) - dTw * Mv[i][6 + cc];
         }
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
+        for (int k = i; k < 3; ++k) {
+            T acc = QLE_PS(3 + i, 3 + k);
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                QLE_PN(i, 12 + c) = M1[i][9 + c];
-                QLE_PN(i, 9 + c) = M1[i][6 + c];
-                QLE_PN(i, 6 + c) = (M1[i][3] * Rt[c][0] + M1[i][4] * Rt[c][1] + M1[i][5] * Rt[c][2]) - dTw * M1[i][9 + c];
-                T acc = M1[i][c];
+            for (int m = 0; m < 6; ++m) acc += X[i][m] * QLE_PS(3 + k, 6 + m);
 #pragma unroll
-                for (int m = 0; m < 6; ++m) acc += M1[i][3 + m] * X[c][m];
-                QLE_PN(i, 3 + c) = acc;
-            }
-#pragma unroll
-            for (int k = i; k < 3; ++k) QLE_PN(i, k) = QLE_PS(i, k) + dT * (QLE_PS(k, 3 + i) + M1[i][k]);
+            for (int m = 0; m < 6; ++m) acc += Mv[i][m] * X[k][m];
+            acc += C[3 * i] * nz.Q[0] * C[3 * k] + C[3 * i + 1] * nz.Q[1] * C[3 * k + 1] + C[3 * i + 2] * nz.Q[2] * C[3 * k + 2];
+            QLE_PN(3 + i, 3 + k) = acc;
         }
     }
-    done(3);
+}
+// level 3: rows r (0..2)
+template <typename T>
+__device__ __forceinline__ void predict_level3(const PredictCtx<T>& c, const T (&P)[120], T (&Pn)[120])
+{
+    const T (&Rt)[3][3] = c.Rt;
+    const T (&X)[3][6] = c.X;
+    const T dT = c.dT, dTw = c.dTw;
+    T M1[3][12];  // M1_r,[v th ab wb] = O_r* + dT O_v*
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int cc = 0; cc < 12; ++cc) M1[i][cc] = QLE_PS(i, 3 + cc) + dT * QLE_PS(3 + i, 3 + cc);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+            QLE_PN(i, 12 + cc) = M1[i][9 + cc];
+            QLE_PN(i, 9 + cc) = M1[i][6 + cc];
+            QLE_PN(i, 6 + cc) = (M1[i][3] * Rt[cc][0] + M1[i][4] * Rt[cc][1] + M1[i][5] * Rt[cc][2]) - dTw * M1[i][9 + cc];
+            T acc = M1[i][cc];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc += M1[i][3 + m] * X[cc][m];
+            QLE_PN(i, 3 + cc) = acc;
+        }
+#pragma unroll
+        for (int k = i; k < 3; ++k) QLE_PN(i, k) = QLE_PS(i, k) + dT * (QLE_PS(k, 3 + i) + M1[i][k]);
+    }
+}
 #undef QLE_PN
+
+// `done(level)` is called after each level (-1: x is final) so the caller can issue that level's stores while the loads of the
+// rows above are still in flight (the caller issues the loads bottom-up too).
+template <typename T, typename Done>
+__device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], const T (&P)[120],
+                                                   const T (&u)[6], T (&accel)[3], T (&Pn)[120], Done done)
+{
+    PredictCtx<T> c;
+    predict_nominal<T>(p, nz, x, u, accel, c);
+    done(-1);  // x is final
+    predict_jacobians<T>(p, c);
+    predict_level0<T>(nz, P, Pn);
+    done(0);
+    predict_level1<T>(c, nz, P, Pn);
+    done(1);
+    predict_level2<T>(c, nz, P, Pn);
+    done(2);
+    predict_level3<T>(c, P, Pn);
+    done(3);
 }
 
 // ------------------------------------------------------------------- update

@@ -1,0 +1,149 @@
+// ekf_fused.hpp -- one single-rate filter_update tick (predict + correction, EKF.cpp:238-249, 265-290) for one lane as ONE
+// straight-line schedule.  gfx950 (CDNA4).  Written so that a host compiler accepts it too: the test suite compiles the arithmetic
+// headers into a CPU checker of its own; the product never does.
+//
+// Why: a lone wave per SIMD (65 536 filters) pays ~9 cycles for every DEPENDENT instruction and 2.5-4 for an independent one
+// (profiles/r02_tuning.md section 3).  The tick has four long dependent scalar chains -- the nominal-state propagation (quaternion
+// exponential), the innovation (quaternion logarithm), R_k with the L D L^T factor of S = G P G^T + R_k (six dependent divisions)
+// and the injection -- and ~1 900 independent covariance FMAs.  Run one after the other (predict, then `if (corrects)` the whole
+// correction) the chains are exposed; here everything up to the factor is unconditional and lives in one basic block, in an order
+// that puts independent covariance work next to each chain:
+//
+//   nominal state            | (loads of P in flight)
+//   innovation, R_k, Gx      | need the predicted nominal state only
+//   level 3 (rows r), level 1 (rows th) of the levelled predict: the blocks S needs -- P(r,r), P(r,th), P(th,th)
+//   S = L D L^T, D^-1 L^-1 dy | next to level 2 (rows v, the largest level) and level 0
+//   lanes that correct:  P <- P - V D^-1 V^T bottom-up in memory order, V = (P G^T) L^-T formed row-block by row-block when the
+//                        downdate first needs it, every 16-byte quad stored as soon as it is final; then dx = V yd and the injection
+//   lanes that do not:   store the predicted state
+//
+// Forming V lazily works because the entries W = P G^T is read from -- P(r, *), P(th, *), P(v, th) -- all sit in block-rows at
+// or above the one whose rows of V are being formed, and the downdate reaches those words later (descending memory order is
+// block-row 4 first).  At most 120 + 36 covariance-sized values are live at the start of the downdate and P shrinks as V grows,
+// instead of P + all of V (210) in the ascending form.
+//
+// Values: the same expressions as ekf_predict_levels + quad::update_* (the cooperative kernel's scalar parts), evaluated in another
+// order.  Measured (profiles/r02_tuning.md section 7): against "levelled predict, then `if (corrects)` the sequential fusion"
+// 65 536 fp32 filters 15.4 -> 13.3 us, fp64 38.3 -> 28.0 us and no scratch in fp64 (direct method; 348 B/lane before).
+#pragma once
+
+#include <type_traits>
+
+#include "ekf_device.hpp"
+#include "ekf_quad.hpp"
+
+namespace qle {
+
+// f(std::integral_constant<int, I>) for I = B .. E-1, unrolled by the template machinery rather than by the loop unroller.
+template <int B, int E, typename F>
+__host__ __device__ __forceinline__ void static_for(F&& f)
+{
+    if constexpr (B < E) {
+        f(std::integral_constant<int, B>{});
+        static_for<B + 1, E>(f);
+    }
+}
+
+// Last word (in memory order) that holds an element of block-row b: the first one a descending sweep meets.
+__host__ __device__ constexpr int block_row_last_word(int b)
+{
+    int r = -1;
+    for (int w = 0; w < 120; ++w)
+        if (word_block_row(w) == b) r = w;
+    return r;
+}
+
+// x: state at tick n-1 in, state at tick n out.  Po: covariance at tick n-1.  `corr`: this lane fuses the tag pose z; `live`: the
+// filter is initialised (a lane that is not stores nothing: corr implies live).
+// emit_accel(accel) / emit_obs(obs): side outputs as soon as they exist.  store_quad(q4, ptr to 4 final words): 4-word group q4 of
+// the new covariance is final (called for q4 = 29 .. 0 on every lane); store_x(): x is final.
+template <typename T, bool DIRECT, typename EmitAccel, typename EmitObs, typename StoreX, typename StoreQuad>
+__device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Noise<T>& nzl, T (&x)[16], const T (&Po)[120], const T (&u)[6],
+                                               const T (&z)[7], bool corr, bool live, EmitAccel&& emit_accel, EmitObs&& emit_obs,
+                                               StoreX&& store_x, StoreQuad&& store_quad)
+{
+    using SQ = quad::ScalarQ<T>;
+    constexpr int kPW_ = 120;
+    T Pn[kPW_];
+    PredictCtx<T> c;
+    {
+        T accel[3];
+        predict_nominal<T>(p, nzl, x, u, accel, c);
+        emit_accel(accel);
+    }
+    // correction, the parts that need only the predicted nominal state
+    quad::NoiseV<T> nz;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) nz.R[k] = nzl.R[k];
+    quad::FactorIn<T> in;
+    quad::update_innovation<SQ, T, DIRECT>(p, x, z, in.dy_, emit_obs);
+    predict_jacobians<T>(p, c);
+    quad::update_noise<SQ, T, DIRECT>(p, nz, x, in.gx, in.rk);
+    // the rows S is read from
+    predict_level3<T>(c, Po, Pn);
+    predict_level1<T>(c, nzl, Po, Pn);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            in.frr[3 * i + k] = Pn[sidx(i, k)]; in.frt[3 * i + k] = Pn[sidx(i, 6 + k)]; in.ftt[3 * i + k] = Pn[sidx(6 + i, 6 + k)];
+        }
+    }
+    quad::UpdU<T> f;
+    quad::update_factor<SQ, DIRECT>(in, f);
+    predict_level2<T>(c, nzl, Po, Pn);
+    predict_level0<T>(nzl, Po, Pn);
+
+    if (corr) {
+        T V[15][6], NV[15][6];
+        static_for<0, kPW_>([&](auto wc) {   // a compile-time loop: every index below must be a constant (no array may reach scratch)
+            constexpr int w = kPW_ - 1 - decltype(wc)::value;
+            constexpr int i = word_row(w), k = word_col(w), b = i / 3;
+            if constexpr (w == block_row_last_word(b)) {   // rows 3b .. 3b+2 of V = (P G^T) L^-T and of -V D^-1, from words not yet touched
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    const int a = 3 * b + r;
+                    T (&v)[6] = V[a];
+#pragma unroll
+                    for (int kk = 0; kk < 3; ++kk) { v[kk] = Pn[sidx(a, kk)]; v[3 + kk] = Pn[sidx(a, 6 + kk)]; }
+                    if (!DIRECT) {
+#pragma unroll
+                        for (int kk = 0; kk < 3; ++kk) v[kk] += v[3] * f.Gx[3 * kk] + v[4] * f.Gx[3 * kk + 1] + v[5] * f.Gx[3 * kk + 2];
+                    }
+#pragma unroll
+                    for (int m = 1; m < 6; ++m) {
+#pragma unroll
+                        for (int m2 = 0; m2 < m; ++m2) v[m] -= f.Lm[quad::lm_idx(m, m2)] * v[m2];
+                    }
+#pragma unroll
+                    for (int m = 0; m < 6; ++m) NV[a][m] = v[m] * (-f.invd[m]);
+                }
+            }
+            // P(i,k) += sum_m (-V(i,m)/d_m) V(k,m)
+            T acc = Pn[w];
+#pragma unroll
+            for (int m = 0; m < 6; ++m) acc += NV[i][m] * V[k][m];
+            Pn[w] = acc;
+            if constexpr (w % 4 == 0) store_quad(w / 4, &Pn[w]);
+        });
+        // inject, EKF.cpp:486-501
+        T dx[15];
+#pragma unroll
+        for (int a = 0; a < 15; ++a) {
+            T acc = V[a][0] * f.yd[0];
+#pragma unroll
+            for (int m = 1; m < 6; ++m) acc += V[a][m] * f.yd[m];
+            dx[a] = acc;
+        }
+        quad::update_inject<SQ, T>(p, x, dx);
+        store_x();
+    } else if (live) {
+        store_x();
+        static_for<0, kPW_ / 4>([&](auto qc) {
+            constexpr int q4 = kPW_ / 4 - 1 - decltype(qc)::value;
+            store_quad(q4, &Pn[4 * q4]);
+        });
+    }
+}
+
+}  // namespace qle

@@ -54,7 +54,6 @@ struct qle_batch {
     int32_t split = 0;        // nt == 3: which workgroups keep their tiles cached (cached_workgroup() in ekf_kernels.hpp)
     int32_t nt_refresh = 0;   // > 0: nt == 1 and the state is <= 40 MiB: non-temporal stores, cached-store tick every nt_refresh ticks
     int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal, 3 split
-    bool step_batch = true;  // k_step: correction in batch form with streamed stores (ekf_update_batch); QLE_STEP_BATCH=0: sequential fusion
     int32_t quad = 0;      // workgroup-cooperative tick kernel (ekf_quad_kernels.hpp): bit 0 ticks with tag poses, bit 1 predict-only ticks
     size_t wsz = 4;
     qle_params pub;

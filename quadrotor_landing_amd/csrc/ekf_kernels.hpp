@@ -20,10 +20,9 @@
 // anchors: see k_step_mr); the last 8 words of the record are padding.
 #pragma once
 
-#include <type_traits>
-
 #include "ekf_device.hpp"
 #include "ekf_quad.hpp"
+#include "ekf_fused.hpp"
 
 namespace qle {
 
@@ -265,90 +264,6 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
     return false;
 }
 
-// f(std::integral_constant<int, I>) for I = B .. E-1, unrolled by the template machinery rather than by the loop unroller.
-template <int B, int E, typename F>
-__device__ __forceinline__ void static_for(F&& f)
-{
-    if constexpr (B < E) {
-        f(std::integral_constant<int, B>{});
-        static_for<B + 1, E>(f);
-    }
-}
-
-// ------------------------------------------------ correction, batch form
-// correction_step (EKF.cpp:417-502) for one lane in BATCH form: S = G P G^T + R_k = L D L^T, V = (P G^T) L^-T, dx = V D^-1 L^-1 dy,
-// P <- P - V D^-1 V^T -- the same factored form the workgroup-cooperative kernel uses (its scalar parts are reused from
-// ekf_quad.hpp), on one lane's packed covariance.  Unlike the sequential fusion of ekf_update_apply, where no entry of P is final
-// before the sixth rank-1 update, the downdated entries are produced here one memory quad after the other and
-// `store_quad(q)` is called as soon as quad q is complete, so the 30 covariance stores stream out while the remaining ~700 FMAs
-// are still being computed instead of draining after the last instruction (k_step: profiles/r02_tuning.md
-// section 7).  `store_x()` is called once the injected nominal state is final.  Both dtypes (fp64: 348 -> 20 B of scratch per lane).
-template <typename T, bool DIRECT, typename EmitObs, typename StoreX, typename StoreQuad>
-__device__ __forceinline__ void ekf_update_batch(const DevParams<T>& p, const Noise<T>& nzl, T (&x)[16], T (&P)[kPW], const T (&z)[7],
-                                                 EmitObs&& emit_obs, StoreX&& store_x, StoreQuad&& store_quad)
-{
-    using SQ = quad::ScalarQ<T>;
-    quad::NoiseV<T> nz;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) nz.R[k] = nzl.R[k];
-    quad::FactorIn<T> in;
-    quad::update_innovation<SQ, T, DIRECT>(p, x, z, in.dy_, emit_obs);
-    quad::update_noise<SQ, T, DIRECT>(p, nz, x, in.gx, in.rk);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { in.frr[3 * i + k] = QLE_PS(i, k); in.frt[3 * i + k] = QLE_PS(i, 6 + k); in.ftt[3 * i + k] = QLE_PS(6 + i, 6 + k); }
-    }
-    quad::UpdU<T> f;
-    quad::update_factor<SQ, DIRECT>(in, f);
-    // V = (P G^T) L^-T, row by row
-    T V[15][6];
-#pragma unroll
-    for (int a = 0; a < 15; ++a) {
-#pragma unroll
-        for (int k = 0; k < 3; ++k) { V[a][k] = QLE_PS(a, k); V[a][3 + k] = QLE_PS(a, 6 + k); }
-        if (!DIRECT) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) V[a][k] += V[a][3] * f.Gx[3 * k] + V[a][4] * f.Gx[3 * k + 1] + V[a][5] * f.Gx[3 * k + 2];
-        }
-#pragma unroll
-        for (int m = 1; m < 6; ++m) {
-#pragma unroll
-            for (int m2 = 0; m2 < m; ++m2) V[a][m] -= f.Lm[quad::lm_idx(m, m2)] * V[a][m2];
-        }
-    }
-    {   // inject, EKF.cpp:486-501
-        T dx[15];
-#pragma unroll
-        for (int a = 0; a < 15; ++a) {
-            T acc = V[a][0] * f.yd[0];
-#pragma unroll
-            for (int m = 1; m < 6; ++m) acc += V[a][m] * f.yd[m];
-            dx[a] = acc;
-        }
-        quad::update_inject<SQ, T>(p, x, dx);
-        store_x();
-    }
-    // P(i,k) += sum_m (-V(i,m)/d_m) V(k,m), in memory order; the scaled rows of a block-row are formed when its first word comes up
-    T nvs[3][6];
-    static_for<0, kPW>([&](auto wc) {   // a compile-time loop: every index below must be a constant (no array may reach scratch)
-        constexpr int w = decltype(wc)::value;
-        constexpr int i = word_row(w), k = word_col(w), b = i / 3;
-        if constexpr (w == 0 || word_block_row(w) != word_block_row(w > 0 ? w - 1 : 0)) {   // first word of block-row b
-#pragma unroll
-            for (int r = 0; r < 3; ++r) {
-#pragma unroll
-                for (int m = 0; m < 6; ++m) nvs[r][m] = V[3 * b + r][m] * (-f.invd[m]);
-            }
-        }
-        T acc = P[w];
-#pragma unroll
-        for (int m = 0; m < 6; ++m) acc += nvs[i % 3][m] * V[k][m];
-        P[w] = acc;
-        if constexpr (w % 4 == 3) store_quad(w / 4);
-    });
-}
-
 // ------------------------------------------------------------- hot kernels
 // Predict tick: reads x16 + P120 + u6, writes x16 + P120 (278 words/filter).
 // Packed P (sidx in ekf_device.hpp): the words of block-row r come first, then v, th, ab, wb.
@@ -448,21 +363,22 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
     }
 }
 
-// Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290):
-// predict, then correct where the record's mask word is non-zero.
+// Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290): predict, then correct where the record's mask word is
+// non-zero, as one straight-line schedule (ekf_step_fused, ekf_fused.hpp).
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
-// BU: the correction in batch form with its stores streamed (ekf_update_batch) instead of the sequential fusion.
-template <typename T, bool DIRECT, bool PFP, bool GATE, int NT, bool BU>
+template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
 __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParams& gp, T* st, const T* __restrict__ us,
                                           const T* __restrict__ zs, const T* __restrict__ pfp,
                                           T* __restrict__ aux_accel, T* __restrict__ aux_obs,
                                           int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t i)
 {
-    T x[kXW], Po[kPW], P[kPW], u[kUW], zr[kZW], accel[3];
+    using Q = typename Quad<T>::type;
+    constexpr int VW = Quad<T>::VW;
+    T x[kXW], Po[kPW], u[kUW], zr[kZW];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
     load_rec<T, kZW, 0, kZW, NT>(zs, i, zr);
     load_rec<T, kSW, 0, kXW, NT>(st, i, x);
-    load_P_quads_desc<T, 0, kPW / Quad<T>::VW, NT>(st, i, Po);
+    load_rec<T, kSW, kXW, kPW, NT>(st, i, Po);   // ascending: the fused schedule starts with rows r
     const bool dead = filter_uninitialised(x);   // left untouched; no early exit (see predict_tick)
     if (dead) x[9] = T(1);
     bool corr = !dead && zr[7] != T(0);
@@ -479,55 +395,34 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     }
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
-    ekf_predict_levels<T>(p, nz, x, Po, u, accel, P, [](int) {});
-    if (aux_accel && !dead) {  // optional side outputs (wave-uniform), written as soon as they exist
+    const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+    T* tb = st + wave_tile(i) * (int64_t)(kSW * kTile);
+    const int lane = (int)(i & 63);
+    ekf_step_fused<T, DIRECT>(p, nz, x, Po, u, z, corr, !dead,
+        [&](const T (&accel)[3]) {
+            if (aux_accel && !dead) {   // optional side outputs (wave-uniform), written as soon as they exist
 #pragma unroll
-        for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
-    }
-    if (BU) {
-        if (corr) {
-            using Q = typename Quad<T>::type;
-            constexpr int VW = Quad<T>::VW;
-            const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-            const int64_t tile = wave_tile(i);
-            T* tb = st + tile * (int64_t)(kSW * kTile);
-            const int lane = (int)(i & 63);
-            ekf_update_batch<T, DIRECT>(p, nz, x, P, z,
-                [&](const T (&obs)[7]) {
-                    if (aux_accel) {
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
-                    }
-                },
-                [&]() { store_rec<T, kSW, 0, kXW, NT>(st, i, x); },
-                [&](int q4) {   // q4 = index of a 4-word group of P; one 16-byte quad in fp32
-#pragma unroll
-                    for (int h = 0; h < 4 / VW; ++h) {
-                        const int qr = kXW / VW + q4 * (4 / VW) + h;
-                        st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + (qr * kTile + lane) * VW), pack_quad(&P[4 * q4 + h * VW]));
-                    }
-                });
-            return;
-        }
-    } else if (corr) {
-        // Measured (profiles/r02_tuning.md): running ekf_update_prepare before the predict's covariance work -- while the loads are
-        // in flight -- does not shorten the tick at 65 536 filters (15.4 us either way) and costs the second wave per SIMD at larger
-        // batches (59 vs 51 us at 262 144 filters), so the correction runs after the predict.
-        T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-        ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&obs)[7]) {
+                for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
+            }
+        },
+        [&](const T (&obs)[7]) {
             if (aux_accel) {
 #pragma unroll
                 for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
             }
+        },
+        [&]() { store_rec<T, kSW, 0, kXW, NT>(st, i, x); },
+        [&](int q4, const T* w4) {   // q4 = index of a 4-word group of P; one 16-byte quad in fp32, two in fp64
+#pragma unroll
+            for (int h = 4 / VW - 1; h >= 0; --h) {
+                const int qr = kXW / VW + q4 * (4 / VW) + h;
+                st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + (qr * kTile + lane) * VW), pack_quad(w4 + h * VW));
+            }
         });
-    }
-    if (dead) return;
-    store_rec<T, kSW, 0, kXW, NT>(st, i, x);
-    store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
 }
 
-template <typename T, bool DIRECT, bool PFP, bool GATE, int NT, bool BU = false>
-__global__ __launch_bounds__(kBlock, (BU || sizeof(T) == 8) ? 1 : 2) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
+template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
                                                  const T* __restrict__ zs, const T* __restrict__ pfp,
                                                  T* __restrict__ aux_accel, T* __restrict__ aux_obs,
                                                  int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
@@ -535,10 +430,10 @@ __global__ __launch_bounds__(kBlock, (BU || sizeof(T) == 8) ? 1 : 2) void k_step
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {   // see k_predict
-        if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0, BU>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
-        else step_tick<T, DIRECT, PFP, GATE, 2, BU>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        else step_tick<T, DIRECT, PFP, GATE, 2>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
     } else {
-        step_tick<T, DIRECT, PFP, GATE, NT, BU>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        step_tick<T, DIRECT, PFP, GATE, NT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
     }
 }
 

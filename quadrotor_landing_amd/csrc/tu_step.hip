@@ -14,14 +14,11 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     const dim3 g = grid_for(h, h->block), b(h->block);
     T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_STEP_LAUNCH(F, N, U) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N, U>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split)
-#define QLE_STEP_U(N, U) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N, U); else QLE_STEP_LAUNCH(false, N, U); } while (0)
-    // fp32: the correction in batch form with streamed stores (ekf_update_batch) where the policy says so; fp64 keeps the sequential form
-#define QLE_STEP_N(N) do { if (h->step_batch) QLE_STEP_U(N, true); else QLE_STEP_U(N, false); } while (0)
+#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split)
+#define QLE_STEP_N(N) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N); else QLE_STEP_LAUNCH(false, N); } while (0)
     const int nt = effective_nt(h);
     if (nt == 3) QLE_STEP_N(3); else if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);
 #undef QLE_STEP_N
-#undef QLE_STEP_U
 #undef QLE_STEP_LAUNCH
     HIP_TRY(hipGetLastError());
     return QLE_OK;
