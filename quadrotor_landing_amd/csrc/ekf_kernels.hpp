@@ -539,6 +539,11 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     }
     if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
     load_rec<T, kSW, kXW, kPW>(sp, i, P);
+    // The IMU sample of the NEXT replayed tick is loaded one step ahead: the ring was streamed to HBM, and a load issued where its
+    // value is needed would expose that latency once per replayed prediction (12-20 times per correcting tick).  Slots are clamped
+    // to the newest written one so that the address is always valid; the current tick's sample comes from `u`.
+    T un[kHW];
+    load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, start + 1 < m.tick ? start + 1 : m.tick - 1), i, un);
     for (int32_t t = start;;) {
         if (corr && t == mt) {                                // the entry the measurement belongs to
             const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
@@ -553,8 +558,9 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         }
         if (t == m.tick) break;
         ++t;                                                  // EKF.cpp:222-226, then :249
-        T uk[kHW] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
-        if (t != m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t), i, uk);
+        const bool now = t == m.tick;
+        const T uk[kHW] = {now ? u[0] : un[0], now ? u[1] : un[1], now ? u[2] : un[2], now ? u[3] : un[3], now ? u[4] : un[4], now ? u[5] : un[5], T(0), T(0)};
+        load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t + 1 < m.tick ? t + 1 : m.tick - 1), i, un);
         const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
         ekf_predict<T>(p, nz, x, P, u6, accel);
         if (t == m.tick) {
