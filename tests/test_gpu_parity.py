@@ -437,6 +437,47 @@ def test_launch_rules_do_not_change_results_large_ragged_batch(monkeypatch, kern
             monkeypatch.delenv(k)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("direct", [0, 1])
+def test_fused_tick_lanes_are_independent_and_predict_only_lanes_match_k_predict(monkeypatch, dtype, direct):
+    """k_step runs predict and correction as ONE schedule with the scalar parts of the correction computed unconditionally
+    (ekf_fused.hpp).  What a lane stores must not depend on that: a lane whose mask word is clear ends up with exactly the bits of the
+    predict-only kernel, a lane whose mask word is set with exactly the bits it gets when every lane corrects -- whatever its
+    neighbours in the wave do, and whatever garbage the tag record of a non-correcting lane holds."""
+    monkeypatch.setenv("QLE_QUAD", "0")   # the one-lane kernels are what is under test
+    kw = dict(golden_kwargs("rotors400"), direct_orien_method=direct)
+    po, pq = both(**kw)
+    rng = np.random.default_rng(911 + direct)
+    B = 64 * 5 + 17
+    x0, P0 = rand_states(rng, B, 15)
+    u = rand_imu(rng, B)
+    z = meas_near(rng, po, oracle_predict_batch(po, x0, P0, u)[0], ang=0.3, pos=0.1)
+    mask = (rng.uniform(size=B) < 0.5).astype(np.uint8)
+    mask[:64] = 1; mask[64:128] = 0                       # one wave that corrects throughout, one that does not at all
+    zg = z.copy()
+    zg[mask == 0] = 0.0                                   # an all-zero tag record (zero quaternion): NaN in the discarded scalar parts
+
+    def tick(kind):
+        e = qla.BatchedRelativePoseEKF(B, dtype, params=pq)
+        e.set_state(x0, P0)
+        if kind == "predict":
+            e.predict(u)
+        elif kind == "all":
+            e.step(u, z, np.ones(B, np.uint8))
+        else:
+            e.step(u, zg, mask)
+        assert e.count_nonfinite() == 0
+        out = e.get_state()
+        e.close()
+        return out
+
+    xp, Pp = tick("predict"); xa, Pa = tick("all"); xm, Pm = tick("mixed")
+    c = mask.astype(bool)
+    np.testing.assert_array_equal(xm[~c], xp[~c]); np.testing.assert_array_equal(Pm[~c], Pp[~c])
+    np.testing.assert_array_equal(xm[c], xa[c]); np.testing.assert_array_equal(Pm[c], Pa[c])
+    assert np.abs(xa - xp).max() > 1e-3                   # the correction did something
+
+
 # ------------------------------------------- filter_update decision logic
 HW_TAGS = dict(
     n_tags=13, tag_in_view_margin=0.0,
