@@ -441,9 +441,10 @@ def test_launch_rules_do_not_change_results_large_ragged_batch(monkeypatch, kern
 @pytest.mark.parametrize("direct", [0, 1])
 def test_fused_tick_lanes_are_independent_and_predict_only_lanes_match_k_predict(monkeypatch, dtype, direct):
     """k_step runs predict and correction as ONE schedule with the scalar parts of the correction computed unconditionally
-    (ekf_fused.hpp).  What a lane stores must not depend on that: a lane whose mask word is clear ends up with exactly the bits of the
-    predict-only kernel, a lane whose mask word is set with exactly the bits it gets when every lane corrects -- whatever its
-    neighbours in the wave do, and whatever garbage the tag record of a non-correcting lane holds."""
+    (ekf_fused.hpp).  What a lane stores must not depend on that: a lane whose mask word is set ends up with exactly the bits it gets
+    when every lane corrects and a lane whose mask word is clear with exactly the bits it gets when none does -- whatever its
+    neighbours in the wave do, and whatever garbage the tag record of a non-correcting lane holds -- and the latter agree with the
+    predict-only kernel to rounding (same expressions, compiled in another kernel: the contraction into FMAs may differ)."""
     monkeypatch.setenv("QLE_QUAD", "0")   # the one-lane kernels are what is under test
     kw = dict(golden_kwargs("rotors400"), direct_orien_method=direct)
     po, pq = both(**kw)
@@ -464,6 +465,8 @@ def test_fused_tick_lanes_are_independent_and_predict_only_lanes_match_k_predict
             e.predict(u)
         elif kind == "all":
             e.step(u, z, np.ones(B, np.uint8))
+        elif kind == "none":
+            e.step(u, zg, np.zeros(B, np.uint8))
         else:
             e.step(u, zg, mask)
         assert e.count_nonfinite() == 0
@@ -471,10 +474,12 @@ def test_fused_tick_lanes_are_independent_and_predict_only_lanes_match_k_predict
         e.close()
         return out
 
-    xp, Pp = tick("predict"); xa, Pa = tick("all"); xm, Pm = tick("mixed")
+    xp, Pp = tick("predict"); xa, Pa = tick("all"); xn, Pn = tick("none"); xm, Pm = tick("mixed")
     c = mask.astype(bool)
-    np.testing.assert_array_equal(xm[~c], xp[~c]); np.testing.assert_array_equal(Pm[~c], Pp[~c])
+    np.testing.assert_array_equal(xm[~c], xn[~c]); np.testing.assert_array_equal(Pm[~c], Pn[~c])
     np.testing.assert_array_equal(xm[c], xa[c]); np.testing.assert_array_equal(Pm[c], Pa[c])
+    tol = 1e-13 if dtype == "f64" else 2e-6
+    np.testing.assert_allclose(xn, xp, rtol=tol, atol=tol); np.testing.assert_allclose(Pn, Pp, rtol=tol, atol=tol)
     assert np.abs(xa - xp).max() > 1e-3                   # the correction did something
 
 
