@@ -96,7 +96,7 @@ def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
     dt_struct = time.perf_counter() - t0
     return {"value": n_filters * n_ticks / dt_all, "unit": "EKF ticks/s", "cores": nthr, "kind": "port",
             "structured": {"value": n_filters * n_ticks / dt_struct, "unit": "EKF ticks/s", "cores": nthr, "dtype": "f32",
-                           "note": "structure-exploiting CPU variant: the engine's per-filter arithmetic (ekf_device.hpp) compiled by g++ -O3 "
+                           "note": "structure-exploiting CPU variant: the engine's per-filter arithmetic (ekf_device.hpp) compiled for the host by ROCm's clang++ -O3 "
                                    "(oracle/ekf_structured_cpu.cpp), same sample, OpenMP static split"},
             "sample": f"{n_filters} filters x {n_ticks} ticks of the cfg3 sequence (fp64, dense reference-shaped arithmetic, OpenMP static split)",
             "single_thread_value": n1 * n_ticks / dt_one, "host_cpus": os.cpu_count()}

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle
+import oracle.synth_np as synth_np
 import quadrotor_landing_amd as qla
 from util import assert_state_close, meas_near, quat_err, rand_imu, rand_states
 
@@ -198,4 +199,58 @@ def test_filters_initialise_on_their_own_first_detection(dtype, multirate, kerne
             else:
                 assert_state_close(xg[inited], Pg[inited], xr, Pr, 2e-3, 2e-3, 2e-3)
     assert inited.sum() == B - 4 and n_perf > B
+    ekf.close()
+
+
+@pytest.mark.parametrize("case", [dict(dtype="f64", perturb=False, delay=0, est_bias=1), dict(dtype="f64", perturb=True, delay=7, est_bias=1),
+                                  dict(dtype="f32", perturb=True, delay=0, est_bias=1), dict(dtype="f64", perturb=False, delay=3, est_bias=0)])
+def test_device_generator_against_host_restatement(case, kernel_family):
+    """The synthetic source that replaces the node's two ROS topics (k_synth, synth_kernels.hpp) against its numpy
+    restatement (oracle/synth_np.py): every IMU record, every tag pose (incl. the delayed ones of multirate runs), the
+    seeding pose, the per-filter parameters of cfg 5, the truth and the true biases of a shard at a non-zero global filter
+    offset, a ragged batch.  fp64 generation on both sides; the device's sin / cos / log / sqrt / pow are not correctly
+    rounded, so agreement is to 1e-12 (fp64 storage) or to fp32 rounding of the stored values."""
+    if kernel_family != "default":
+        pytest.skip("the generator does not depend on the tick kernels")
+    B, T, off = 64 * 3 + 21, 45, 1000003
+    kw = dict(CFG3, est_bias=case["est_bias"], ab_static=[0.2, -0.09, -0.03], wb_static=[-0.02, -0.01, 0.0],
+              q_vc=[-0.7035177, 0.7106742, 0.0014521, -0.0017207], r_v_cv=[0.06036412, -0.00145196, -0.04439579])
+    if not case["est_bias"]:
+        kw.pop("Q_ab"); kw.pop("Q_wb")
+    thm = np.zeros(T, np.uint8); thm[4::7] = 1; thm[0] = 1
+    ekf = qla.BatchedRelativePoseEKF(B, case["dtype"], **kw)
+    seq = ekf.make_inputs(T, thm)
+    ekf.synth_generate(seq, seed=0xC0FFEE123, filter_offset=off, perturb_filter_params=case["perturb"], meas_delay_ticks=case["delay"])
+    ref = synth_np.generate(oracle.make_params(**kw), B, thm, seed=0xC0FFEE123, filter_offset=off, perturb_filter_params=case["perturb"],
+                            meas_delay_ticks=case["delay"])
+    f32 = case["dtype"] == "f32"
+    rt = 3e-7 if f32 else 1e-12
+
+    def close(a, b, what):
+        np.testing.assert_allclose(a, b, rtol=rt, atol=rt, err_msg=what)
+
+    slot = 0
+    for t in range(T):
+        u, z, m = seq.download_tick(t)
+        close(u, ref["u"][t], f"IMU record of tick {t}")
+        if thm[t]:
+            assert m.all()
+            assert quat_err(z[:, 3:], ref["z"][slot][:, 3:]) < (1e-6 if f32 else 1e-12)
+            close(z[:, :3], ref["z"][slot][:, :3], f"tag position of tick {t}")
+            slot += 1
+    pose, bias = ekf.synth_truth(seq)                    # kept in fp64 on the device whatever the compute dtype
+    np.testing.assert_allclose(pose[:, :3], ref["truth"][:, :3], rtol=1e-12, atol=1e-12)
+    assert quat_err(pose[:, 3:], ref["truth"][:, 3:]) < 1e-12
+    np.testing.assert_allclose(bias, ref["truth_bias"], rtol=1e-12, atol=1e-14)
+    if case["perturb"]:
+        close(ekf.get_filter_params(), ref["pfp"], "per-filter parameters")
+    # the filters were seeded from the generator's pre-sequence tag pose: initialize_state of the oracle on the restated pose
+    x0, _ = ekf.get_state()
+    po = oracle.make_params(**kw)
+    for i in (0, 17, B - 1):
+        f = oracle.Filter(po)
+        f.set_apriltag(ref["z0"][i, :3], ref["z0"][i, 3:], 0.0)
+        xs = f.x()
+        assert quat_err(x0[i:i + 1, 6:10], xs[None, 6:10]) < (2e-6 if f32 else 1e-11)
+        np.testing.assert_allclose(x0[i, :3], xs[:3], rtol=2e-6 if f32 else 1e-11, atol=2e-6 if f32 else 1e-11)
     ekf.close()

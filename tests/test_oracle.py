@@ -414,3 +414,29 @@ def test_structured_cpu_build_against_reference_twin_sequences(golden_dir, ps, v
         assert qclose(x[0, 6:10], xr[6:10], tol * 10)
         np.testing.assert_allclose(np.delete(x[0], range(6, 10)), np.delete(xr, range(6, 10)), rtol=tol, atol=tol)
         np.testing.assert_allclose(np.diag(P[0]), d[f"{ps}__P_diag_seq"][T - 1], rtol=tol * 10)
+
+
+# ---------------- the host restatement of the synthetic source (oracle/synth_np.py)
+def test_synth_restatement_counter_rng_and_sharding():
+    """The counter-based generator of the synthetic source, restated on the host: splitmix64 finaliser against its published test
+    vector, uniforms inside (0, 1) with the right moments, and the property the sharding rests on -- a filter's data depends on its
+    GLOBAL index only, so any split of a population over shards reproduces the single-process sequence bit for bit."""
+    import oracle.synth_np as sn
+    # splitmix64 (Steele, Lea, Flood 2014): mix(gamma) is the generator's first output from state 0
+    assert int(sn.mix64(np.uint64(0x9E3779B97F4A7C15))) == 0xE220A8397B1DCDAF
+    gi = np.arange(20000)
+    uu = sn.rng_uniform(7, gi, 3, 5)
+    assert uu.min() > 0.0 and uu.max() < 1.0 and abs(uu.mean() - 0.5) < 0.01 and abs(uu.std() - 12 ** -0.5) < 0.01
+    nn = sn.rng_normal(7, gi, 3, 5)
+    assert abs(nn.mean()) < 0.03 and abs(nn.std() - 1.0) < 0.03
+    assert not np.array_equal(sn.rng_uniform(7, gi, 3, 5), sn.rng_uniform(7, gi, 4, 5))
+    p = oracle.make_params(update_freq=400.0, est_bias=1)
+    thm = np.zeros(12, np.uint8); thm[3::4] = 1
+    whole = sn.generate(p, 96, thm, seed=11, filter_offset=1000, perturb_filter_params=True, meas_delay_ticks=2)
+    part = sn.generate(p, 32, thm, seed=11, filter_offset=1032, perturb_filter_params=True, meas_delay_ticks=2)
+    for k in ("u", "z"):
+        np.testing.assert_array_equal(part[k], whole[k][:, 32:64])
+    for k in ("z0", "pfp", "truth", "truth_bias"):
+        np.testing.assert_array_equal(part[k], whole[k][32:64])
+    assert np.allclose(np.linalg.norm(whole["z"][..., 3:], axis=-1), 1.0) and np.allclose(np.linalg.norm(whole["truth"][:, 3:], axis=1), 1.0)
+    assert abs(np.linalg.norm(whole["u"][..., :3], axis=-1).mean() - 9.81) < 0.5   # specific force ~ g
