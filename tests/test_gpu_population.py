@@ -254,3 +254,50 @@ def test_device_generator_against_host_restatement(case, kernel_family):
         assert quat_err(x0[i:i + 1, 6:10], xs[None, 6:10]) < (2e-6 if f32 else 1e-11)
         np.testing.assert_allclose(x0[i, :3], xs[:3], rtol=2e-6 if f32 else 1e-11, atol=2e-6 if f32 else 1e-11)
     ekf.close()
+
+
+@pytest.mark.parametrize("cfg", [dict(name="cfg4", B=1048576, perturb=False, shard=131072), dict(name="cfg5", B=262144, perturb=True, shard=32768)])
+def test_baseline_populations_at_full_size(cfg, kernel_family):
+    """BASELINE cfg 4 (1 048 576 fp32 filters) and cfg 5 (262 144 fp32 filters with perturbed per-filter parameters) at their FULL
+    global population on one device, through size-independent properties: no non-finite filter, unit quaternions, positive
+    variances; one eighth of the population run as its own shard (its own handle, global filter offset, the cache policy of its
+    smaller state) reproduces its slice of the whole population BIT FOR BIT -- which is what the 8-device form of these
+    configurations rests on; a strided slice agrees with the oracle run on the downloaded inputs (and per-filter parameters); the
+    per-device RMSE reduction equals a host computation on the downloaded state and truth."""
+    if kernel_family != "default":
+        pytest.skip("full-size populations use the default policy")
+    B, Bs, T = cfg["B"], cfg["shard"], 28
+    rank = 5
+    thm = np.zeros(T, np.uint8); thm[13::14] = 1
+    po = oracle.make_params(**CFG3)
+
+    def run(n, offset, keep_inputs):
+        e = qla.BatchedRelativePoseEKF(n, "f32", **CFG3)
+        s = e.make_inputs(T, thm)
+        e.synth_generate(s, seed=0xE4F00044, filter_offset=offset, perturb_filter_params=cfg["perturb"])
+        x0, P0 = (e.get_state() if keep_inputs else (None, None))
+        e.run(s, 0, T)
+        assert e.count_nonfinite() == 0
+        out = dict(x0=x0, P0=P0, state=e.get_state(), rmse=e.synth_rmse(s), truth=e.synth_truth(s)[0])
+        if keep_inputs:
+            out["pfp"] = e.get_filter_params() if cfg["perturb"] else None
+            out["ticks"] = [s.download_tick(t) for t in range(T)]
+        e.close()
+        return out
+
+    whole = run(B, 0, False)
+    xg, Pg = whole["state"]
+    np.testing.assert_allclose(np.linalg.norm(xg[:, 6:10], axis=1), 1.0, atol=1e-5)
+    assert np.all(np.einsum("bii->bi", Pg) > 0)
+    np.testing.assert_allclose(whole["rmse"], _host_rmse_sums(xg, whole["truth"]), rtol=1e-10)
+    assert whole["rmse"][2] == B and np.sqrt(whole["rmse"][0] / B) < 0.5 and np.sqrt(whole["rmse"][1] / B) < 0.5
+    part = run(Bs, rank * Bs, True)
+    sl = slice(rank * Bs, (rank + 1) * Bs)
+    np.testing.assert_array_equal(part["state"][0], xg[sl]); np.testing.assert_array_equal(part["state"][1], Pg[sl])
+    np.testing.assert_array_equal(part["truth"], whole["truth"][sl])
+    del whole, xg, Pg
+    idx = np.arange(0, Bs, 256)
+    U = np.stack([t[0][idx] for t in part["ticks"]]); Z = np.stack([t[1][idx] for t in part["ticks"]]); M = np.stack([t[2][idx] for t in part["ticks"]])
+    xr, Pr = oracle.run_batch(po, part["x0"][idx], part["P0"][idx], U, Z, M, per_filter_params=part["pfp"][idx] if cfg["perturb"] else None)
+    assert_state_close(part["state"][0][idx], part["state"][1][idx], xr, Pr, 5e-3, 5e-3, 5e-3)
+    assert M.sum() == 2 * idx.size
