@@ -5,9 +5,11 @@
 // Why: a lone wave per SIMD (65 536 filters) pays ~9 cycles for every DEPENDENT instruction and 2.5-4 for an independent one
 // (profiles/r02_tuning.md section 3).  The tick has four long dependent scalar chains -- the nominal-state propagation (quaternion
 // exponential), the innovation (quaternion logarithm), R_k with the L D L^T factor of S = G P G^T + R_k (six dependent divisions)
-// and the injection -- and ~1 900 independent covariance FMAs.  Run one after the other (predict, then `if (corrects)` the whole
-// correction) the chains are exposed; here everything up to the factor is unconditional and lives in one basic block, in an order
-// that puts independent covariance work next to each chain:
+// and the injection -- and ~1 900 independent covariance FMAs.  Everything up to the factor is written unconditionally, in an order
+// that puts independent covariance work next to each chain, and the downdate streams its stores.  Measured (section 7 there): the
+// streamed stores and the lower register pressure are what pays (fp32 15.4 -> 13.3 us at 65 536 filters, fp64 38.3 -> 28.0 us and no
+// scratch); the placement of the chains does not -- the compiler sinks the factor back under the branch and a lone wave is bound by
+// the number of instructions it issues, not by their dependencies.
 //
 //   nominal state            | (loads of P in flight)
 //   innovation, R_k, Gx      | need the predicted nominal state only
@@ -23,8 +25,7 @@
 // instead of P + all of V (210) in the ascending form.
 //
 // Values: the same expressions as ekf_predict_levels + quad::update_* (the cooperative kernel's scalar parts), evaluated in another
-// order.  Measured (profiles/r02_tuning.md section 7): against "levelled predict, then `if (corrects)` the sequential fusion"
-// 65 536 fp32 filters 15.4 -> 13.3 us, fp64 38.3 -> 28.0 us and no scratch in fp64 (direct method; 348 B/lane before).
+// order.
 #pragma once
 
 #include <type_traits>
