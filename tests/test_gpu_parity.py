@@ -223,6 +223,58 @@ def test_per_filter_params_cfg5():
     ekf.close()
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_randomized_configurations_short_runs_vs_oracle(dtype):
+    """16 randomly drawn parameter sets -- both orientation methods, with and without bias states, update rates 50-800 Hz, noise
+    levels over four decades, random camera mounting (q_vc, r_v_cv), static biases, gravity -- each on a 96-filter batch run for
+    8 ticks (predict-only ticks, fully and partly masked corrections) with special inputs mixed in: exactly zero and
+    sub-tolerance gyro rates (the small-angle branches of EKF.cpp:383-395 and QH.cpp:16-24), innovations of up to ~170 degrees (the
+    quaternion flip of QH.cpp:70-72), identity attitude, large and tiny covariances.  Engine vs oracle after every run."""
+    rng = np.random.default_rng(20261004)
+    B, T = 96, 8
+    for case in range(16):
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        kw = dict(update_freq=float(rng.choice([50.0, 100.0, 400.0, 800.0])), direct_orien_method=int(case % 2), est_bias=int((case // 2) % 2),
+                  Q_a=list(10 ** rng.uniform(-5, -1, size=3)), Q_w=list(10 ** rng.uniform(-6, -2, size=3)),
+                  R_r=list(10 ** rng.uniform(-4, -1, size=3)), R_ang=list(10 ** rng.uniform(-4, -1, size=3)),
+                  q_vc=list(q), r_v_cv=list(rng.normal(size=3) * 0.1), ab_static=list(rng.normal(size=3) * 0.2),
+                  wb_static=list(rng.normal(size=3) * 0.02), g=[0.0, 0.0, float(rng.choice([-9.8, -9.81, -1.62]))])
+        if kw["est_bias"]:
+            kw.update(Q_ab=list(10 ** rng.uniform(-7, -3, size=3)), Q_wb=list(10 ** rng.uniform(-8, -4, size=3)))
+        po, pq = both(**kw)
+        n = po.num_states
+        x, P = rand_states(rng, B, n, cov_scale=float(10 ** rng.uniform(-3, 0.5)))
+        x[:8, 6:10] = np.array([0.0, 0.0, 0.0, 1.0])                     # identity attitude
+        if not kw["est_bias"]:
+            x[:, 10:16] = 0.0
+        U = np.stack([rand_imu(rng, B) for _ in range(T)])
+        U[:, 8:16, 3:6] = x[8:16, 13:16] + np.array(kw["wb_static"])                                       # w - wb - wb_static == 0
+        U[:, 16:24, 3:6] = x[16:24, 13:16] + np.array(kw["wb_static"]) + 1e-11 * kw["update_freq"]            # |dT w| = 1e-11 < small_ang_tol
+        M = (rng.uniform(size=(T, B)) < 0.5).astype(np.uint8); M[0] = 0; M[1] = 1
+        Z = np.zeros((T, B, 7)); Z[..., 6] = 1.0
+        if dtype == "f32":
+            x, P, U = (a.astype(np.float32).astype(np.float64) for a in (x, P, U))
+        ekf = qla.BatchedRelativePoseEKF(B, dtype, params=pq)
+        ekf.set_state(x, P)
+        xr, Pr = x.copy(), P.copy()
+        for t in range(T):
+            xp, Pp = oracle.run_batch(po, xr, Pr, U[t][None], n_threads=1)  # where the filters will be after this tick's predict
+            z = meas_near(rng, po, xp, ang=0.4, pos=0.1)
+            z[24:40] = meas_near(rng, po, xp[24:40], ang=2.9, pos=0.1)      # innovations into the flip region
+            if dtype == "f32":
+                z = z.astype(np.float32).astype(np.float64)
+            Z[t] = z
+            ekf.step(U[t], z, M[t])
+            xr, Pr = oracle.run_batch(po, xr, Pr, U[t][None], z[None], M[t][None], n_threads=1)
+        xg, Pg = ekf.get_state()
+        assert ekf.count_nonfinite() == 0
+        if dtype == "f64":
+            assert_state_close(xg, Pg, xr, Pr, 1e-9, 1e-11, 1e-9)
+        else:
+            assert_state_close(xg, Pg, xr, Pr, 2e-3, 2e-3, 2e-3)
+        ekf.close()
+
+
 # -------------------------------------------------------- cfg 2: free run
 def test_cfg2_free_run_fp64_4096():
     """BASELINE cfg 2: B=4096 fp64, update on every tick; 1000-tick free run vs the oracle."""
