@@ -1,8 +1,8 @@
-# fused tick with dx formed row by row and the injection started inside the downdate sweep
+# fused tick with a scheduling barrier in front of each lazy formation of V rows
 mkdir -p gpurun_out/s2
-L=gpurun_out/s2/inject_early.log; : > $L
+L=gpurun_out/s2/lazy_barrier.log; : > $L
 for a in "4096 f32" "16384 f32" "65536 f32" "131072 f32" "262144 f32" "4096 f64" "16384 f64" "65536 f64" "262144 f64"; do
-  QLE_QUAD=0 timeout -k 10 200 python profiles/time_kernels.py $a inject_early >> $L 2>&1
+  QLE_QUAD=0 timeout -k 10 200 python profiles/time_kernels.py $a lazy_barrier >> $L 2>&1
 done
 cat $L
 timeout -k 10 800 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
