@@ -12,11 +12,12 @@
 // the number of instructions it issues, not by their dependencies.
 //
 //   nominal state            | (loads of P in flight)
-//   innovation, R_k, Gx      | need the predicted nominal state only
+//   R_k, Gx                  | need the predicted nominal state only
 //   level 3 (rows r), level 1 (rows th) of the levelled predict: the blocks S needs -- P(r,r), P(r,th), P(th,th)
-//   S = L D L^T, D^-1 L^-1 dy | next to level 2 (rows v, the largest level) and level 0
+//   S = L D L^T              | next to level 2 (rows v, the largest level) and level 0
 //   lanes that correct:  P <- P - V D^-1 V^T bottom-up in memory order, V = (P G^T) L^-T formed row-block by row-block when the
-//                        downdate first needs it, every 16-byte quad stored as soon as it is final; then dx = V yd and the injection
+//                        downdate first needs it, every 16-byte quad stored as soon as it is final; then -- under the drain of those
+//                        stores -- the innovation dy, its elimination yd = D^-1 L^-1 dy, dx = V yd and the injection
 //   lanes that do not:   store the predicted state
 //
 // Forming V lazily works because the entries W = P G^T is read from -- P(r, *), P(th, *), P(v, th) -- all sit in block-rows at
@@ -77,7 +78,8 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
 #pragma unroll
     for (int k = 0; k < 6; ++k) nz.R[k] = nzl.R[k];
     quad::FactorIn<T> in;
-    quad::update_innovation<SQ, T, DIRECT>(p, x, z, in.dy_, emit_obs);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) in.dy_[k] = T(0);   // the factor below is wanted for L and D only; dy is eliminated after the sweep
     predict_jacobians<T>(p, c);
     quad::update_noise<SQ, T, DIRECT>(p, nz, x, in.gx, in.rk);
     // the rows S is read from
@@ -127,6 +129,27 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
             Pn[w] = acc;
             if constexpr (w % 4 == 0) store_quad(w / 4, &Pn[w]);
         });
+        // Nothing the downdate needs depends on the innovation: dy, its elimination yd = D^-1 L^-1 dy, dx and the injection come AFTER the
+        // sweep, where they run under the drain of the covariance stores.  The tag pose is made to depend on the last covariance word so
+        // that the scheduler cannot pull the chain (quaternion logarithm: ~150 dependent instructions) in front of the first store.
+        {
+            T zz[7] = {z[0], z[1], z[2], z[3], z[4], z[5], z[6]};
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(zz[6]) : "v"(Pn[0]));
+#endif
+            T xp[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) xp[k] = x[k];
+            T dy[6];
+            quad::update_innovation<SQ, T, DIRECT>(p, xp, zz, dy, emit_obs);
+#pragma unroll
+            for (int cc = 0; cc < 6; ++cc) {
+#pragma unroll
+                for (int j = cc + 1; j < 6; ++j) dy[j] = dy[j] - f.Lm[quad::lm_idx(j, cc)] * dy[cc];
+            }
+#pragma unroll
+            for (int m = 0; m < 6; ++m) f.yd[m] = dy[m] * f.invd[m];
+        }
         // inject, EKF.cpp:486-501
         T dx[15];
 #pragma unroll
