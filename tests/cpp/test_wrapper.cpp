@@ -23,7 +23,7 @@ int main(int argc, char** argv)
 {
     const int dtype = (argc > 1 && std::atoi(argv[1]) == 32) ? QLE_F32 : QLE_F64;
     const bool multirate = argc > 2 && std::atoi(argv[2]) != 0;  // the shipped parameter files enable it
-    const double tol = dtype == QLE_F64 ? 1e-9 : 2e-3;
+    const double tol = dtype == QLE_F64 ? 1e-9 : 2e-4;   // 300 ticks; measured deviations: tests/tolerances.md
     try {
         qle_host::RelativePoseEKF ekf(0, dtype);
         // parameters as the node would set them from relative_pose_EKF_rotors.yaml (single-rate)

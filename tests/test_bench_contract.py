@@ -22,6 +22,11 @@ def test_cpu_share_and_argument_defaults():
     assert bench.kernel_name(lanes, "f32", False) == "k_predict<float>" and bench.kernel_name(lanes, "f64", True) == "k_step<double>"
     assert bench.kernel_name(coop, "f64", True) == "kw_tick<double,step>" and bench.kernel_name(coop, "f64", False) == "k_predict<double>"
     assert bench.kernel_name(lanes, "f32", False, mr=True) == "k_predict<float,MR>"
+    # placement is best effort and never raises: without a KFD topology (this container) it says why nothing was pinned
+    before = os.sched_getaffinity(0)
+    pl = bench.pin_to_gpu_numa_node(1, 2)
+    assert isinstance(pl, dict) and "pinned" in pl and (pl["pinned"] or pl["why"])
+    os.sched_setaffinity(0, before)
 
 
 @pytest.mark.gpu
@@ -42,7 +47,8 @@ def test_bench_json_contract(extra):
     assert "workload" in d["config"] and "model" not in d["config"]
     assert d["value"] > 0 and abs(d["value"] - d["config"]["global_batch"] * 42 / (d["ms_per_step"] * 1e-3 * 42)) / d["value"] < 1e-6
     rf = d["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert rf["bound"] in ("hbm", "infinity_cache", "split") and rf["bound"] == rf["served_by"] and rf["bound_class"] == "memory"
+    assert rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and "hbm_frac" in rf
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_us"] * 1e-6) / 1e9) / rf["achieved"] < 1e-6
     assert d["nonfinite_filters"] == 0
@@ -56,6 +62,11 @@ def test_bench_json_contract(extra):
         for sub in ("hbm_resident", "f64_same_batch"):
             assert d[sub]["achieved"] > 0 and d[sub]["nonfinite_filters"] == 0 and d[sub]["served_by"] in ("infinity_cache", "hbm", "split")
         assert d["hbm_resident"]["batch"] == 2097152 and d["hbm_resident"]["served_by"] == "split"
+        hr = d["hbm_resident"]
+        assert 0 < hr["hbm_share"] < 1 and abs(hr["hbm_frac"] - hr["hbm_share"] * hr["achieved"] / 8000.0) < 1e-12
+        assert rf["hbm_frac"] == hr["hbm_frac"] if rf["bound"] != "hbm" else rf["hbm_frac"] == rf["frac"]
+    if "rmse_vs_truth" in d:
+        assert d["rmse_vs_truth"]["wraps_in_timed_regions"] >= 0 and d["rmse_vs_truth"]["ticks"] == d["config"]["ticks_resident_in_hbm"]
         assert d["f64_same_batch"]["dtype"] == "f64" and d["f64_same_batch"]["batch"] == 4096
     if not extra:
         cb = d["cpu_baseline"]
@@ -81,6 +92,19 @@ def test_bench_two_ranks_print_one_json_line():
     assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["scaling"] == "weak"
     assert abs(d["value"] - 8192 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert "cpu_baseline" not in d          # rank 0 at N = 1 only
+    _check_per_rank(d, [4096, 4096], [0, 4096])
+
+
+def _check_per_rank(d, filters, offsets):
+    """What every rank saw on its own survives next to the max-over-ranks figure: shard sizes, global filter offsets, per-rank
+    wall and HIP-event time per step (the reported ms_per_step is their maximum, region by region), CPU placement."""
+    pr = d["per_rank"]
+    n = len(filters)
+    assert pr["filters"] == filters and pr["filter_offset"] == offsets
+    assert len(pr["ms_per_step"]) == n and len(pr["hip_event_ms_per_step"]) == n and len(pr["placement"]) == n
+    assert all(0 < ev <= ms * 1.001 for ev, ms in zip(pr["hip_event_ms_per_step"], pr["ms_per_step"]))
+    assert max(pr["ms_per_step"]) <= d["region_ms"]["max"] / d["steps"] * 1.001
+    assert all(isinstance(p, dict) and "pinned" in p for p in pr["placement"])
 
 
 @pytest.mark.gpu
@@ -98,6 +122,7 @@ def test_bench_strong_scaling_workloads_split_a_fixed_global_batch(workload, glo
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["global_batch"] == glob and d["config"]["batch_per_gpu"] == glob // 2
+    _check_per_rank(d, [glob // 2, glob // 2], [0, glob // 2])
     assert abs(d["value"] - glob / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
     assert d["nonfinite_filters"] == 0
     if workload == "cfg5":

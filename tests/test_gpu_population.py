@@ -3,7 +3,8 @@ perturbed parameters drawn on the device, per-device RMSE reduction) checked aga
 population the device generated, and per-filter state_initialized (filters seeded on their own first detection,
 relative_pose_EKF.cpp:129-130, 305-344; relative_pose_EKF_node.cpp:169-174).
 
-Tolerances: fp32 engine vs fp64 oracle -- one step rtol 2e-5 / atol 2e-6 (state), free run <= 5e-3; fp64 1e-10.
+Tolerances: fp32 engine vs fp64 oracle -- free runs of 28-56 ticks with 2-4 corrections <= 6e-5 (state; measured 4-7e-6), 8e-6 (quaternion;
+8e-7), 2e-4 x sqrt(P_ii P_jj) (covariance; 1-2e-5): tests/tolerances.md; fp64 1e-10.
 """
 import numpy as np
 import pytest
@@ -81,7 +82,7 @@ def test_cfg5_population_as_specified(kernel_family):
         u, z, m = seq.download_tick(t)
         U[t], Z[t], M[t] = u[idx], z[idx], m[idx]
     xr, Pr = oracle.run_batch(po, x0[idx], P0[idx], U, Z, M, per_filter_params=pfp[idx])
-    assert_state_close(xg[idx], Pg[idx], xr, Pr, 5e-3, 5e-3, 5e-3)
+    assert_state_close(xg[idx], Pg[idx], xr, Pr, 6e-5, 6e-5, 8e-6, ptol=2e-4)
     assert M.sum() == 4 * idx.size
     # (iv) the per-device RMSE reduction against a host computation on the downloaded state and truth
     truth_pose, truth_bias = ekf.synth_truth(seq)
@@ -122,7 +123,7 @@ def test_direct_method_step_with_per_filter_parameters_vs_oracle(dtype, kernel_f
         if dtype == "f64":
             assert_state_close(xg, Pg, xr, Pr, 1e-11, 1e-13, 1e-11)
         else:
-            assert_state_close(xg, Pg, xr, Pr, 2e-5, 2e-6, 2e-6)
+            assert_state_close(xg, Pg, xr, Pr, 5e-6, 5e-6, 2e-6, ptol=3e-4)   # one fused tick: measured 3.5e-7 / 1.3e-7 / 3.5e-5
         ekf.close()
 
 
@@ -197,7 +198,7 @@ def test_filters_initialise_on_their_own_first_detection(dtype, multirate, kerne
             if dtype == "f64":
                 assert_state_close(xg[inited], Pg[inited], xr, Pr, 1e-9, 1e-11, 1e-9)
             else:
-                assert_state_close(xg[inited], Pg[inited], xr, Pr, 2e-3, 2e-3, 2e-3)
+                assert_state_close(xg[inited], Pg[inited], xr, Pr, 6e-5, 6e-5, 8e-6, ptol=2e-4)
     assert inited.sum() == B - 4 and n_perf > B
     ekf.close()
 
@@ -299,5 +300,5 @@ def test_baseline_populations_at_full_size(cfg, kernel_family):
     idx = np.arange(0, Bs, 256)
     U = np.stack([t[0][idx] for t in part["ticks"]]); Z = np.stack([t[1][idx] for t in part["ticks"]]); M = np.stack([t[2][idx] for t in part["ticks"]])
     xr, Pr = oracle.run_batch(po, part["x0"][idx], part["P0"][idx], U, Z, M, per_filter_params=part["pfp"][idx] if cfg["perturb"] else None)
-    assert_state_close(part["state"][0][idx], part["state"][1][idx], xr, Pr, 5e-3, 5e-3, 5e-3)
+    assert_state_close(part["state"][0][idx], part["state"][1][idx], xr, Pr, 6e-5, 6e-5, 8e-6, ptol=2e-4)
     assert M.sum() == 2 * idx.size

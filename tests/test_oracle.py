@@ -314,6 +314,96 @@ def test_full_filter_update_against_reference_twin(golden_dir, mode):
     np.testing.assert_allclose(f.P(), d[f"{mode}__P_final"], rtol=1e-7, atol=1e-11)
 
 
+# ---------------- C++-only branches pinned through the twin by identity (tests/golden/make_golden_branches.py)
+def hw_branch_kwargs(d, **over):
+    """HW.yaml's values for the branches the `hw__*` / `gate__*` / `static__*` fixtures exercise (see make_golden_branches.py)."""
+    kw = dict(update_freq=100.0, measurement_freq=100.0, limit_measurement_freq=0, corner_margin_enbl=1, direct_orien_method=1, est_bias=1,
+              ab_static=d["static__ab_static"], wb_static=d["static__wb_static"],
+              n_tags=13, tag_in_view_margin=float(d["gate__margin"][0]), tag_widths=d["gate__tag_widths"], tag_positions=d["gate__tag_positions"],
+              camera_K=d["gate__camera_K"], camera_width=int(d["gate__camera_size"][0]), camera_height=int(d["gate__camera_size"][1]))
+    kw.update(over)
+    return kw
+
+
+def test_static_bias_predict_against_twin_identity(golden_dir):
+    """EKF.cpp:357-358 (static-bias subtraction) against twin outputs obtained with the statics inside the bias states."""
+    sets = load_param_sets(golden_dir)
+    d = np.load(os.path.join(golden_dir, "branch_cases.npz"))
+    p = orc_params_for("hardware", sets, ab_static=d["static__ab_static"], wb_static=d["static__wb_static"])
+    assert np.abs(np.array(list(p.ab_static))).max() > 0.1
+    for i in range(d["static__x"].shape[0]):
+        xo, Po, acc = oracle.prediction_step(p, d["static__x"][i], d["static__P"][i], d["static__u"][i])
+        xr = d["static__x_check"][i]
+        assert qclose(xo[6:10], xr[6:10], 1e-13)
+        np.testing.assert_allclose(np.delete(xo, range(6, 10)), np.delete(xr, range(6, 10)), rtol=1e-12, atol=1e-14)
+        np.testing.assert_allclose(Po, d["static__P_check"][i], rtol=1e-11, atol=1e-15)
+        np.testing.assert_allclose(acc, d["static__accel"][i], rtol=1e-12, atol=1e-13)
+    # and the statics matter: without them the same call is far off
+    p0 = orc_params_for("hardware", sets)
+    assert np.abs(oracle.prediction_step(p0, d["static__x"][3], d["static__P"][3], d["static__u"][3])[0][3:6] - d["static__x_check"][3][3:6]).max() > 1e-4
+
+
+def test_multi_tag_gate_against_composed_twin_decisions(golden_dir):
+    """EKF.cpp:160-181: the loop over the bundle == `or` over the twin's single-tag decisions; each tag on its own == the twin's."""
+    d = np.load(os.path.join(golden_dir, "branch_cases.npz"))
+    kw = hw_branch_kwargs(d)
+    p13 = oracle.make_params(**kw)
+    Z, per_tag, composed = d["gate__z"], d["gate__per_tag"], d["gate__composed"]
+    assert 0 < composed.sum() < len(composed) and (composed & (1 - per_tag[:, 0])).sum() > 20   # decided by a tag other than the first
+    got = np.array([oracle.corner_gate(p13, z[:3], z[3:]) for z in Z], np.uint8)
+    np.testing.assert_array_equal(got, composed)
+    w, pos = d["gate__tag_widths"], d["gate__tag_positions"].reshape(13, 3)
+    for k in range(13):
+        p1 = oracle.make_params(**dict(kw, n_tags=1, tag_widths=[w[k]], tag_positions=list(pos[k])))
+        got = np.array([oracle.corner_gate(p1, z[:3], z[3:]) for z in Z], np.uint8)
+        np.testing.assert_array_equal(got, per_tag[:, k])
+    pn = ekf_np.Params.from_orc(p13)
+    np.testing.assert_array_equal(np.array([ekf_np.corner_gate(pn, z[:3], z[3:]) for z in Z], np.uint8), composed)
+
+
+@pytest.mark.parametrize("mode", ["hw_multirate", "hw_singlerate"])
+@pytest.mark.parametrize("delay", ["dynamic_exact", "dynamic_clamped", "fixed"])
+def test_hardware_like_filter_update_against_twin(golden_dir, mode, delay):
+    """The oracle's filter_update with everything HW.yaml switches on -- static biases, the 13-tag bundle, a correction on every
+    tick, a 15-tick measurement delay taken from the stamps (EKF.cpp:199-200) -- against the twin's trajectory (identities in
+    tests/golden/make_golden_branches.py).  dynamic_exact: age + offset = 150 ms; dynamic_clamped: age 300 ms, delay_max 150 ms."""
+    d = np.load(os.path.join(golden_dir, "branch_cases.npz"))
+    sets = load_param_sets(golden_dir)
+    s = sets["hardware"]
+    q = s["Q"]
+    dyn = dict(fixed=dict(dynamic_meas_delay=0, measurement_delay=0.150),
+               dynamic_exact=dict(dynamic_meas_delay=1, measurement_delay=0.010, measurement_delay_max=0.350, dyn_measurement_delay_offset=0.085),
+               dynamic_clamped=dict(dynamic_meas_delay=1, measurement_delay=0.010, measurement_delay_max=0.150, dyn_measurement_delay_offset=0.085))[delay]
+    age = float(d[f"{mode}__age_clamped"][0] if delay == "dynamic_clamped" else d[f"{mode}__age_exact"][0])
+    p = oracle.make_params(**hw_branch_kwargs(d, multirate_ekf=int(mode == "hw_multirate"), Q_a=q[0:3], Q_w=q[3:6], Q_ab=q[6:9], Q_wb=q[9:12],
+                                              R_r=s["R"][0:3], R_ang=s["R"][3:6], r_v_cv=s["r_v_cv"], q_vc=s["q_vc"], **dyn))
+    assert p.upd_per_meas == 1
+    U, Z, NEW = d[f"{mode}__u"], d[f"{mode}__z"], d[f"{mode}__new"]
+    f = oracle.Filter(p)
+    z0 = d[f"{mode}__z0"]
+    f.set_apriltag(z0[:3], z0[3:], -1.0)      # seeds the filter (NODE.cpp:169-174)
+    f.f.measurement_ready = 0
+    for t in range(U.shape[0]):
+        tc = 0.01 * t
+        f.set_imu(U[t, :3], U[t, 3:])
+        if NEW[t]:
+            f.set_apriltag(Z[t, :3], Z[t, 3:], tc - age)
+        f.filter_update(tc)
+        assert f.f.performed_correction == d[f"{mode}__perf"][t], t
+        assert f.f.upds_since_correction == d[f"{mode}__upds"][t], t
+        assert f.f.measurement_ready == 0
+        if mode == "hw_multirate":
+            assert f.f.hist_len == d[f"{mode}__hist_len"][t], t
+            if f.f.performed_correction and delay != "fixed":
+                assert abs(f.f.measurement_delay_curr - 0.150) < 1e-12
+        x = f.x()
+        xr = d[f"{mode}__x_seq"][t]
+        assert qclose(x[6:10], xr[6:10], 1e-9), t
+        np.testing.assert_allclose(np.delete(x, range(6, 10)), np.delete(xr, range(6, 10)), rtol=1e-8, atol=1e-9)
+        np.testing.assert_allclose(np.diag(f.P()), d[f"{mode}__P_diag_seq"][t], rtol=1e-8)
+    np.testing.assert_allclose(f.P(), d[f"{mode}__P_full"][-1], rtol=1e-7, atol=1e-11)
+
+
 # ---------------- the engine's block-structured algebra, compiled for the CPU, against the dense oracle
 def engine_cpu_run(variant, p, x, P, U, Z, M, dtype):
     """The engine's per-filter arithmetic compiled for the host: one lane per filter (ekf_device.hpp: levelled or

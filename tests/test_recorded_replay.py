@@ -13,7 +13,7 @@ import pytest
 import oracle
 import quadrotor_landing_amd as qla
 from quadrotor_landing_amd import replay as rp
-from util import GOLDEN, oracle_replay, orc_params_from_qle
+from util import GOLDEN, note, oracle_replay, orc_params_from_qle
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LOG = os.path.join(GOLDEN, "recorded_cfg1.csv")
@@ -102,9 +102,12 @@ def _compare(tr, ref, tol, multirate):
     assert np.array_equal(tr[:, 20], ref[:, 20]) and np.array_equal(tr[:, 21], ref[:, 21])   # same decisions on every tick
     q, qr = tr[:, 7:11], ref[:, 7:11]
     sgn = np.sign(np.sum(q * qr, axis=1, keepdims=True))
+    note("quat", np.abs(q * sgn - qr).max(), tol)
     np.testing.assert_allclose(q * sgn, qr, rtol=0, atol=tol)
     for cols in (slice(1, 7), slice(11, 20)):
+        note("state", (np.abs(tr[:, cols] - ref[:, cols]) / (1 + np.abs(ref[:, cols]))).max(), tol)
         np.testing.assert_allclose(tr[:, cols], ref[:, cols], rtol=tol, atol=tol)
+    note("Pdiag", np.abs(tr[:, 23:25] / ref[:, 23:25] - 1).max(), max(tol * 10, 1e-9))
     np.testing.assert_allclose(tr[:, 23:25], ref[:, 23:25], rtol=max(tol * 10, 1e-9), atol=0)
     if multirate:                                              # measurement_delay_curr is only set by the multirate branch (EKF.cpp:199)
         perf = ref[:, 20] > 0
@@ -113,7 +116,7 @@ def _compare(tr, ref, tol, multirate):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("variant", list(VARIANTS))
-@pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 5e-3)])
+@pytest.mark.parametrize("dtype,tol", [("f64", 1e-9), ("f32", 3e-5)])   # fp32 over 995 ticks, ~150 corrections: measured 2.5e-6 (tests/tolerances.md)
 def test_python_replay_matches_oracle_filter(variant, dtype, tol):
     ref = oracle_replay(orc_params_from_qle(params(variant)), rp.read_event_log(LOG))
     tr, n_corr = _engine_trace(variant, dtype, batch=3)
