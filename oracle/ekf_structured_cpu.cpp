@@ -19,6 +19,7 @@
 #include "../quadrotor_landing_amd/csrc/ekf_device.hpp"
 #include "../quadrotor_landing_amd/csrc/ekf_quad.hpp"
 #include "../quadrotor_landing_amd/csrc/ekf_fused.hpp"
+#include "../quadrotor_landing_amd/csrc/ekf_packed.hpp"
 #include "ekf_oracle.h"
 
 using namespace qle;
@@ -61,9 +62,24 @@ static int64_t run_batch_t(const orc_params* p, int64_t B, int64_t Tn, double* x
         const double* Pi = P + (int64_t)n * n * i;
         for (int a = 0; a < 15; ++a)
             for (int b = a; b < 15; ++b) Pp[sidx(a, b)] = (a < n && b < n) ? (T)(0.5 * (Pi[a * n + b] + Pi[b * n + a])) : T(0);
+        PackedCov<T> Sb;                     // levels == 3: the covariance as register blocks (ekf_packed.hpp), kept across ticks
+        if (levels == 3) cov_pack<T>(Pp, Sb);
         for (int64_t t = 0; t < Tn; ++t) {
             const double* ut = u + (t * B + i) * 6;
             const T uu[6] = {(T)ut[0], (T)ut[1], (T)ut[2], (T)ut[3], (T)ut[4], (T)ut[5]};
+            if (levels == 3) {   // what the multirate replay loop runs: packed predict, blocks unpacked only for a correction
+                ekf_predict_packed<T>(dp, nz, xs, Sb, uu, acc);
+                if (mask && mask[t * B + i]) {
+                    const double* zt = z + (t * B + i) * 7;
+                    const T zz[7] = {(T)zt[0], (T)zt[1], (T)zt[2], (T)zt[3], (T)zt[4], (T)zt[5], (T)zt[6]};
+                    cov_unpack<T>(Sb, Pp);
+                    if (p->direct_orien_method) ekf_update<T, true>(dp, nz, xs, Pp, zz, obs);
+                    else ekf_update<T, false>(dp, nz, xs, Pp, zz, obs);
+                    cov_pack<T>(Pp, Sb);
+                }
+                if (t + 1 == Tn) cov_unpack<T>(Sb, Pp);
+                continue;
+            }
             if (levels == 2) {   // the whole tick as one schedule (ekf_fused.hpp), what k_step runs
                 const bool corr = mask && mask[t * B + i];
                 T zz[7] = {T(0), T(0), T(0), T(0), T(0), T(0), T(1)};

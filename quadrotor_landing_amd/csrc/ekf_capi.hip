@@ -143,7 +143,7 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
         int32_t* hf = nullptr;
         double *stp = nullptr, *dc = nullptr;
         void *mu = nullptr, *mc = nullptr, *ma = nullptr;
-        const size_t ub = (size_t)Cu * kHW * (size_t)h->Bp * h->wsz, cb = (size_t)Nc * slot_bytes(h);
+        const size_t ub = (size_t)Cu * kHW * (size_t)h->Bp * h->wsz, cb = (size_t)(Nc + 1) * slot_bytes(h);   // Nc grid checkpoints + the extra one
         hipError_t e = hipMalloc((void**)&hf, sizeof(int32_t) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMalloc((void**)&stp, sizeof(double) * (size_t)h->Bp);
         if (e == hipSuccess) e = hipMalloc((void**)&dc, sizeof(double) * (size_t)h->Bp);
@@ -293,7 +293,7 @@ extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
     if (h->pfp_on) words += kFW;
     int64_t bytes = words * (int64_t)h->wsz * h->B;
     // a multirate predict tick also appends to the history: the IMU sample (6 words + 2 pad) and, every mr_k-th tick, a checkpoint
-    if (h->mr && kind == 0) bytes += (int64_t)((kHW + 136.0 / h->mr_k) * (double)h->wsz * (double)h->B);
+    if (h->mr && kind == 0) bytes += (int64_t)((kHW + 136.0 / h->mr_k + (h->e_period > 0 ? 136.0 / (double)h->e_period : 0.0)) * (double)h->wsz * (double)h->B);
     return bytes;
 }
 
@@ -305,10 +305,10 @@ extern "C" int qle_get_policy(const qle_batch* h, qle_policy* out)
     out->split_k64 = h->nt == 3 ? -h->split : 0;
     out->block = h->block;
     out->coop_ticks = h->mr ? 0 : h->quad;
-    out->ring_slots = h->mr ? h->mr_Nc : 1;
+    out->ring_slots = h->mr ? h->mr_Nc + 1 : 1;
     out->state_bytes = (int64_t)slot_bytes(h);
     // what a tick touches again later: the state itself, plus (multirate) the history it streams to
-    out->ring_bytes = (int64_t)slot_bytes(h) * (h->mr ? (2 + h->mr_Nc) : 1) + (h->mr ? (int64_t)h->mr_Cu * kHW * h->Bp * (int64_t)h->wsz : 0);
+    out->ring_bytes = (int64_t)slot_bytes(h) * (h->mr ? (3 + h->mr_Nc) : 1) + (h->mr ? (int64_t)h->mr_Cu * kHW * h->Bp * (int64_t)h->wsz : 0);
     return QLE_OK;
 }
 
@@ -499,6 +499,8 @@ int mr_prepare(qle_batch* h)
         hipLaunchKernelGGL(k_fill_i32<int32_t>, grid_for(h, 256), dim3(256), 0, h->stream, h->hist_first, (int32_t)(h->tick - 1), h->B);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->mr_anchor, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream));
+        h->e_tick = h->e_want = h->last_mr_launch = -1;
+        h->e_period = 0;
     }
     h->hist_dirty = false;
     return QLE_OK;
@@ -542,6 +544,8 @@ static int advance_tick(qle_batch* h)
             }
         h->tick -= shift;
         h->flags_tick -= shift;
+        for (int64_t* tk : {&h->e_tick, &h->e_want, &h->last_mr_launch})
+            if (*tk >= 0) *tk = std::max<int64_t>(*tk - shift, -1);
         h->tick_origin += shift;
     }
     return QLE_OK;

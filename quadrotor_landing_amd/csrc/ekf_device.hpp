@@ -285,12 +285,11 @@ __device__ __forceinline__ void predict_jacobians(const DevParams<T>& p, Predict
 // The covariance part of prediction_step, in place: P <- L3 (L2 (L1 P L1^T) L2^T) L3^T + W Q W^T as three symmetric congruences on the
 // packed upper triangle.
 template <typename T>
-__device__ __forceinline__ void predict_cov_inplace(const PredictCtx<T>& ctx, const Noise<T>& nz, T (&P)[120])
+__device__ __forceinline__ void predict_cov_inplace_noq(const PredictCtx<T>& ctx, T (&P)[120])
 {
     const T dT = ctx.dT, dTw = ctx.dTw;
     const T (&X)[3][6] = ctx.X;
     const T (&Rt)[3][3] = ctx.Rt;
-    const T (&C)[9] = ctx.C;
     // ---- congruence 1: r <- r + dT v -------------------------------------
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -415,6 +414,12 @@ __device__ __forceinline__ void predict_cov_inplace(const PredictCtx<T>& ctx, co
         }
     }
 
+}
+template <typename T>
+__device__ __forceinline__ void predict_cov_inplace(const PredictCtx<T>& ctx, const Noise<T>& nz, T (&P)[120])
+{
+    predict_cov_inplace_noq<T>(ctx, P);
+    const T (&C)[9] = ctx.C;
     // ---- W Q W^T, EKF.cpp:402-414: blockdiag(0, C Qa C^T, Qw, Qab, Qwb) ----
 #pragma unroll
     for (int i = 0; i < 3; ++i) {

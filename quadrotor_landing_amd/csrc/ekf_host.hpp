@@ -92,6 +92,11 @@ struct qle_batch {
     void* mr_ckpt = nullptr;       // state checkpoints: mr_Nc slots, one per mr_k ticks
     void* mr_anchor = nullptr;     // one state slot: every filter's corrected entry at hist_first
     int32_t mr_k = 16, mr_Nc = 0, mr_Cu = 0;
+    // the extra checkpoint (slot mr_Nc), placed at the expected entry of the next measurement (k_step_mr, ekf_kernels.hpp)
+    int64_t e_tick = -1;           // tick whose state the slot holds, -1 = none
+    int64_t e_want = -1;           // the predict launch of this tick fills it, -1 = none scheduled
+    int64_t last_mr_launch = -1;   // tick of the last launch of k_step_mr (the cadence of the tag poses as the host sees it)
+    int64_t e_period = 0;          // that cadence in ticks while the extra checkpoint is being scheduled, else 0 (byte accounting)
     double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
     double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
     double t_curr = 0.0, uniform_age = 0.0;
@@ -189,6 +194,7 @@ static inline MrParams make_mr(const qle_batch* h)
     m.fixed_step = h->der.measurement_step_delay;
     m.dynamic = h->pub.dynamic_meas_delay;
     m.gate = h->gating ? 1 : 0;
+    m.e_tick = h->e_tick >= 0 ? (int32_t)h->e_tick : -(1 << 30);
     m.slot_words = (int64_t)kSW * h->Bp;
     m.u_words = (int64_t)kHW * h->Bp;
     m.dT = h->der.dT_nom;
@@ -209,6 +215,35 @@ static inline void* mr_ck_slot_host(const qle_batch* h, int64_t t)
 {
     if (t < 0 || t % h->mr_k != 0) return nullptr;
     return (char*)h->mr_ckpt + slot_bytes(h) * (size_t)((t / h->mr_k) % h->mr_Nc);
+}
+// the checkpoint copy a predict launch of tick t makes, if any: the grid slot, or the extra slot when t is the tick it was scheduled for
+static inline void* mr_ck_for_predict(qle_batch* h, int64_t t)
+{
+    if (void* grid = mr_ck_slot_host(h, t)) {
+        if (t == h->e_want) h->e_want = -1;          // the grid checkpoint of this tick serves
+        return grid;
+    }
+    if (t >= 0 && t == h->e_want) {
+        h->e_want = -1;
+        h->e_tick = t;
+        return (char*)h->mr_ckpt + slot_bytes(h) * (size_t)h->mr_Nc;
+    }
+    return nullptr;
+}
+// after a launch of k_step_mr at tick n: where will the entry of the NEXT tag poses be?
+static inline void mr_schedule_extra(qle_batch* h)
+{
+    const int64_t n = h->tick;
+    const int64_t period = h->last_mr_launch >= 0 ? n - h->last_mr_launch : (int64_t)h->der.upd_per_meas;
+    h->last_mr_launch = n;
+    int64_t step = h->der.measurement_step_delay;                                      // EKF.cpp:93
+    if (h->pub.dynamic_meas_delay && !h->have_stamps)                                  // EKF.cpp:199-200 with the uniform age
+        step = std::max<int64_t>((int64_t)(std::min(h->uniform_age + h->pub.dyn_measurement_delay_offset, h->pub.measurement_delay_max) / h->der.dT_nom + 0.5), 1);
+    const int64_t e = n + period - step;
+    // only an entry that lies AFTER this tick is worth a copy (a longer delay than the cadence puts it inside the replayed range,
+    // one tick after the anchor), and only while the cadence is short enough for the IMU ring to still hold the samples
+    h->e_want = (e > n && period > 1 && period + step < h->mr_Cu) ? e : -1;
+    h->e_period = h->e_want >= 0 ? period : 0;
 }
 
 // ---- kernel launchers, defined and explicitly instantiated for float and double in the tu_*.hip files ----

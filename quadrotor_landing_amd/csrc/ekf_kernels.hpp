@@ -23,6 +23,7 @@
 #include "ekf_device.hpp"
 #include "ekf_quad.hpp"
 #include "ekf_fused.hpp"
+#include "ekf_packed.hpp"
 
 namespace qle {
 
@@ -449,6 +450,11 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(DevPara
 //   u ring   the IMU sample of every tick, slot t % Cu (8 words per filter and tick);
 //   ckpt     a copy of the state after every k-th tick, slot (t/k) % Nc (Cu = k Nc >= step_max + k + 1);
 //   anchor   per filter the corrected entry of its last correction (tick hist_first[i]) -- the start of its history;
+//   extra    one more checkpoint slot (index Nc) that the host places where it expects the NEXT measurement's entry: tag poses come at
+//            a regular cadence with a near-constant latency, so after a correcting tick n the next entry will be about
+//            n + (ticks between the last two correcting ticks) - (nominal step delay); the predict launch of that tick copies the state
+//            there as well.  A filter whose entry is at or just after it starts from it and replays nothing (or a tick or two) instead of
+//            (k-1)/2 ticks from the grid; a filter it does not fit (another phase, an early pose) never looks at it;
 // and rebuilds the entry a measurement belongs to by replaying at most k-1 predictions from the newest checkpoint in
 // (hist_first, mt], or from the anchor.  The replay towards "now" rewrites the checkpoints it passes, so every checkpoint
 // newer than hist_first always holds the current chain.  Same arithmetic on the same stored samples as the reference's
@@ -462,7 +468,7 @@ struct MrParams {
     int32_t fixed_step;   // measurement_step_delay (EKF.cpp:93) when !dynamic
     int32_t dynamic;      // dynamic_meas_delay (EKF.hpp:79)
     int32_t gate;         // 1: mask word = measurement_ready, decide on device; 0: mask word = perform
-    int32_t _pad;
+    int32_t e_tick;       // tick whose state the EXTRA checkpoint slot (index Nc) holds; far negative = none (see k_step_mr)
     int64_t slot_words;   // words per state slot (kSW x padded batch)
     int64_t u_words;      // words per IMU ring slot (kHW x padded batch)
     double dT, offset, delay_max, t_curr, uniform_age;  // EKF.cpp:199-200
@@ -482,10 +488,81 @@ __device__ __forceinline__ T* mr_ck_slot(T* ckpt, const MrParams& m, int32_t tic
     return ckpt + (int64_t)((tick / m.k) % m.Nc) * m.slot_words;
 }
 
+// Per-wave timeline of k_step_mr (diagnostic build only: make dbg, -DQLE_MR_STAMPS; profiles/r03_scripts/mr_timeline.py reads it back
+// through qle_debug_clocks).  Lane 0 of every wave writes s_memtime at the marked points; each stamp takes a value of the phase before it
+// as an input so that it cannot move.  Slots: 0 entry, 1 inputs and x arrived, 2 chain start decided, 3 chain state arrived, 4 first
+// IMU sample arrived, 5 / 6 correction begin / end, 7 end; 8 + 2 j / 9 + 2 j: IMU sample of loop iteration j ready / its predict done.
+#ifdef QLE_MR_STAMPS
+constexpr int kDbgSlots = 128, kDbgWaves = 4096;
+static __device__ unsigned long long qle_dbg_clock[kDbgWaves * kDbgSlots];
+#define QLE_STAMP(k, dep)                                                                                                  \
+    do {                                                                                                                   \
+        unsigned long long t_;                                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                              \
+        if ((i & 63) == 0 && (i >> 6) < kDbgWaves && (k) < kDbgSlots) qle_dbg_clock[(i >> 6) * kDbgSlots + (k)] = t_;       \
+    } while (0)
+#else
+#define QLE_STAMP(k, dep) do { } while (0)
+#endif
+
+// Minimum of a value over the 64 lanes of the wave, as a wave-uniform (SGPR) value.  Every lane must be active.
+__device__ __forceinline__ int32_t wave_min_i32(int32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t o = __shfl_xor(v, off, 64);
+        v = o < v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
+
 // A multirate tick that carries tag poses.  Lanes that correct: load the newest checkpoint at or before the entry the
 // measurement belongs to (or the anchor), replay up to that entry, fuse the measurement there (the corrected entry becomes the
 // anchor), replay the predictions up to n-1 from the stored IMU samples -- rewriting the checkpoints on the way -- then predict
-// tick n.  Lanes that do not: plain predict of `cur`.  One predict call site serves the replay and the current tick.
+// tick n.  Lanes that do not: plain predict of `cur`.
+//
+// The covariance stays in registers for the whole chain (12-35 predictions), so the kernel is bound by the number of instructions per
+// replayed tick, not by bytes (profiles/r02_tuning.md section 10): the chain runs on the register-block form of ekf_packed.hpp
+// (packed fp32 FMAs, no libm call per tick), and the loop counter is WAVE-UNIFORM -- the wave walks from the earliest entry any of its
+// lanes starts from, a lane joins at its own entry -- so that the history addresses (IMU ring slot, checkpoint slot) are scalar and
+// the "is this the current tick" selects are scalar branches.  One predict call site serves the replay and the current tick.
+// The covariance of a replayed chain as it is held between the ticks of the loop.  fp32: the register blocks of ekf_packed.hpp (two FMAs per
+// instruction).  fp64: the packed triangle itself, advanced in place by the three congruences of ekf_device.hpp -- fp64 has no packed FMA
+// to gain from the block form and its nine-word diagonal blocks would cost 30 registers the kernel does not have -- with the
+// per-tick scalar part of ekf_packed.hpp (no libm call, F[th,th] from the quaternion the nominal state needs anyway).
+template <typename T, bool BLOCKS = (sizeof(T) == 4)> struct MrChain;
+template <typename T> struct MrChain<T, true> {
+    PackedCov<T> S;
+    __device__ __forceinline__ void from_flat(const T (&P)[kPW]) { cov_pack<T>(P, S); }
+    // f(P) on the packed triangle; MODIFIES: f changes P
+    template <bool MODIFIES, typename F> __device__ __forceinline__ void with_flat(F&& f)
+    {
+        T P[kPW];
+        cov_unpack<T>(S, P);
+        f(P);
+        if (MODIFIES) cov_pack<T>(P, S);
+    }
+    __device__ __forceinline__ void predict(const DevParams<T>& p, const Noise<T>& nz, T (&x)[kXW], const T (&u)[kUW], T (&accel)[3])
+    {
+        ekf_predict_packed<T>(p, nz, x, S, u, accel);
+    }
+    __device__ __forceinline__ T probe() const { return S.blk(2, 2).d + S.blk(0, 1).c.x; }   // values a predict forms last (diagnostic stamps)
+};
+template <typename T> struct MrChain<T, false> {
+    T P[kPW];
+    __device__ __forceinline__ void from_flat(const T (&Pf)[kPW])
+    {
+#pragma unroll
+        for (int k = 0; k < kPW; ++k) P[k] = Pf[k];
+    }
+    template <bool MODIFIES, typename F> __device__ __forceinline__ void with_flat(F&& f) { f(P); }   // no second copy of P
+    __device__ __forceinline__ void predict(const DevParams<T>& p, const Noise<T>& nz, T (&x)[kXW], const T (&u)[kUW], T (&accel)[3])
+    {
+        ekf_predict_lean<T>(p, nz, x, P, u, accel);
+    }
+    __device__ __forceinline__ T probe() const { return P[sidx(8, 8)] + P[sidx(0, 5)]; }
+};
+
 template <typename T, bool DIRECT, bool PFP>
 __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* cur, T* uring, T* ckpt, T* anchor,
                                                     const T* __restrict__ us, const T* __restrict__ zs, const T* __restrict__ pfp,
@@ -494,18 +571,25 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
                                                     double* __restrict__ delay_out, int64_t B)
 {
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
-    if (i >= B) return;
-    T x[kXW], P[kPW], u[kUW], accel[3] = {T(0), T(0), T(0)};
+    if ((i & ~(int64_t)63) >= B) return;             // the whole wave lies beyond the batch (wave-uniform)
+    // from here on all 64 lanes stay active (the record arrays are allocated in whole tiles; a lane beyond B sees a zeroed,
+    // i.e. not initialised, filter and never touches the per-filter scalar arrays)
+    T x[kXW], u[kUW], accel[3] = {T(0), T(0), T(0)};
+    QLE_STAMP(0, (T)(i & 63));
     load_rec<T, kUW, 0, kUW>(us, i, u);
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
     T zr[kZW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
     load_rec<T, kSW, 0, kXW>(cur, i, x);
-    if (filter_uninitialised(x)) return;
-    bool corr = zr[7] != T(0);
-    if (m.gate) {  // EKF.cpp:147-186
-        const bool consume = corr && (!gp.limit || (gp.tick - last_corr[i]) >= gp.upd_per_meas);
+    // the per-filter history indices are requested with the records above, not after them (they depend on nothing but i)
+    const int32_t first_i = i < B ? hist_first[i] : 0;
+    const int32_t lastc_i = (m.gate && i < B) ? last_corr[i] : 0;
+    QLE_STAMP(1, x[9] + zr[7] + u[5]);
+    const bool valid = i < B && !filter_uninitialised(x);   // EKF.cpp:129-130
+    bool corr = valid && zr[7] != T(0);
+    if (m.gate && valid) {  // EKF.cpp:147-186
+        const bool consume = corr && (!gp.limit || (gp.tick - lastc_i) >= gp.upd_per_meas);
         bool ok = consume;
         if (consume && gp.corner_enbl) {
             const double zd[7] = {(double)zr[0], (double)zr[1], (double)zr[2], (double)zr[3], (double)zr[4], (double)zr[5], (double)zr[6]};
@@ -527,7 +611,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
             step = (int32_t)(dcur / m.dT + 0.5);
             if (step < 1) step = 1;
         }
-        const int32_t first = hist_first[i];
+        const int32_t first = first_i;
         const int32_t len = m.tick - first;    // entries first .. n-1
         int32_t ind = len - step;
         if (ind < 0) ind = 0;
@@ -535,46 +619,80 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         const int32_t c0 = floor_div(mt, m.k) * m.k;   // newest checkpoint tick <= mt
         if (c0 > first) { start = c0; sp = mr_ck_slot(ckpt, m, c0); }
         else { start = first; sp = anchor; }
+        // the extra checkpoint, written where the host expected this measurement's entry (a regular cadence: no pre-replay at all)
+        if (m.e_tick > start && m.e_tick <= mt) { start = m.e_tick; sp = ckpt + (int64_t)m.Nc * m.slot_words; }
         hist_first[i] = mt;                    // EKF.cpp:214-219
     }
-    if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
-    load_rec<T, kSW, kXW, kPW>(sp, i, P);
-    // The IMU sample of the NEXT replayed tick is loaded one step ahead: the ring was streamed to HBM, and a load issued where its
-    // value is needed would expose that latency once per replayed prediction (12-20 times per correcting tick).  Slots are clamped
-    // to the newest written one so that the address is always valid; the current tick's sample comes from `u`.
+    const int32_t t_lo = wave_min_i32(valid ? start : 0x7fffffff);
+    if (t_lo == 0x7fffffff) return;            // no initialised filter in this wave (wave-uniform)
+    QLE_STAMP(2, (T)start);
+    MrChain<T> S;
+    {
+        T P[kPW];
+        if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
+        load_rec<T, kSW, kXW, kPW>(sp, i, P);
+        S.from_flat(P);
+        QLE_STAMP(3, P[0] + P[119] + x[0]);
+    }
+    // The IMU sample of the NEXT replayed tick is requested one step ahead (wave-uniform slot address).  One step of arithmetic (~1.8 us)
+    // covers the latency of the ring, which was streamed to HBM; requesting the whole window up front instead (LDS-DMA into a per-wave LDS
+    // window, profiles/r03_tuning.md) made the loop 4 % shorter and the prologue 15 000 cycles longer: the requests of all waves arrive
+    // at once and queue behind one another.
     T un[kHW];
-    load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, start + 1 < m.tick ? start + 1 : m.tick - 1), i, un);
-    for (int32_t t = start;;) {
+    if (t_lo + 1 < m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t_lo + 1), i, un);
+    int dbg_j = 0;
+    (void)dbg_j;
+    for (int32_t t = t_lo;;) {                 // t is wave-uniform
         if (corr && t == mt) {                                // the entry the measurement belongs to
+            QLE_STAMP(5, x[0]);
             const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-            ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&o)[7]) {   // EKF.cpp:209
-                if (aux_accel) {
+            S.template with_flat<true>([&](T (&P)[kPW]) {
+                ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&o)[7]) {   // EKF.cpp:209
+                    if (aux_accel) {
 #pragma unroll
-                    for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
-                }
+                        for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
+                    }
+                });
+                store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
+                store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
             });
-            store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
-            store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
+            QLE_STAMP(6, x[0]);
         }
         if (t == m.tick) break;
         ++t;                                                  // EKF.cpp:222-226, then :249
-        const bool now = t == m.tick;
-        const T uk[kHW] = {now ? u[0] : un[0], now ? u[1] : un[1], now ? u[2] : un[2], now ? u[3] : un[3], now ? u[4] : un[4], now ? u[5] : un[5], T(0), T(0)};
-        load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t + 1 < m.tick ? t + 1 : m.tick - 1), i, un);
-        const T u6[kUW] = {uk[0], uk[1], uk[2], uk[3], uk[4], uk[5]};
-        ekf_predict<T>(p, nz, x, P, u6, accel);
-        if (t == m.tick) {
-            store_rec<T, kSW, 0, kXW>(cur, i, x);
-            store_rec<T, kSW, kXW, kPW>(cur, i, P);
-            store_rec<T, kHW, 0, kHW, 2>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
+        const bool now = t == m.tick;                         // wave-uniform
+        T u6[kUW];
+#pragma unroll
+        for (int k = 0; k < kUW; ++k) u6[k] = now ? u[k] : un[k];   // `now` is wave-uniform: a scalar select
+        QLE_STAMP(8 + 2 * dbg_j, u6[0] + u6[5]);
+        if (t + 1 < m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t + 1), i, un);
+        if (valid && t > start) {
+            S.predict(p, nz, x, u6, accel);
+            QLE_STAMP(9 + 2 * dbg_j, x[0] + x[9] + S.probe());
+            const bool extra = t == m.e_tick;                 // wave-uniform
+            const bool ck = (t % m.k == 0 || extra) && (now || (corr && t > mt));   // checkpoints of the rewritten part of the chain
+            if (now || ck) {
+                S.template with_flat<false>([&](const T (&P)[kPW]) {
+                    if (now) {
+                        store_rec<T, kSW, 0, kXW>(cur, i, x);
+                        store_rec<T, kSW, kXW, kPW>(cur, i, P);
+                        const T uk[kHW] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+                        store_rec<T, kHW, 0, kHW, 2>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
+                    }
+                    if (ck) {
+                        T* ckp = extra ? ckpt + (int64_t)m.Nc * m.slot_words : mr_ck_slot(ckpt, m, t);
+                        store_rec<T, kSW, 0, kXW, 2>(ckp, i, x);
+                        store_rec<T, kSW, kXW, kPW, 2>(ckp, i, P);
+                    }
+                });
+            }
         }
-        if (t % m.k == 0 && (t == m.tick || (corr && t > mt))) {   // checkpoints of the rewritten part of the chain
-            T* ck = mr_ck_slot(ckpt, m, t);
-            store_rec<T, kSW, 0, kXW, 2>(ck, i, x);
-            store_rec<T, kSW, kXW, kPW, 2>(ck, i, P);
-        }
+#ifdef QLE_MR_STAMPS
+        ++dbg_j;
+#endif
     }
-    if (aux_accel) {
+    QLE_STAMP(7, x[0]);
+    if (aux_accel && valid) {
 #pragma unroll
         for (int k = 0; k < 3; ++k) aux_accel[i * 3 + k] = accel[k];
     }

@@ -94,11 +94,25 @@ template <typename T, bool SYM = false> __device__ __forceinline__ void m3_axpy(
     o.c += sp * S.c;
     o.d += s * S.d;
 }
-// o(A) += C S(A)
-template <typename T, bool SYM = false> __device__ __forceinline__ void m3_lmulAA(M3<T>& o, const C3<T>& C, const M3<T>& S)
+// acc (+)= a * b: SET starts the accumulator with the product (no zero to initialise, no add of a zero)
+template <bool SET, typename V> __device__ __forceinline__ void pk_mac(V& acc, const V& a, const V& b)
 {
+    if (SET) acc = a * b;
+    else acc += a * b;
+}
+// o(A) += C S(A)      (SET: o(A) = C S(A))
+template <typename T, bool SYM = false, bool SET = false> __device__ __forceinline__ void m3_lmulAA(M3<T>& o, const C3<T>& C, const M3<T>& S)
+{
+    {
+        const T s2 = m3_elA(S, 0, 2);
+        pk_mac<SET>(o.a[0], pk_bc(c3_el(C, 0, 0)), S.a[0]);
+        pk_mac<SET>(o.a[1], pk_bc(c3_el(C, 1, 0)), S.a[0]);
+        if (!SYM) pk_mac<SET>(o.a[2], pk_bc(c3_el(C, 2, 0)), S.a[0]);
+        pk_mac<SET>(o.c, C.cc[0], pk_bc(s2));
+        pk_mac<SET>(o.d, C.c2[0], s2);
+    }
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 1; m < 3; ++m) {
         const T s2 = m3_elA(S, m, 2);
         o.a[0] += pk_bc(c3_el(C, 0, m)) * S.a[m];
         o.a[1] += pk_bc(c3_el(C, 1, m)) * S.a[m];
@@ -107,22 +121,31 @@ template <typename T, bool SYM = false> __device__ __forceinline__ void m3_lmulA
         o.d += C.c2[m] * s2;
     }
 }
-// o(R) += C S(A)
-template <typename T> __device__ __forceinline__ void m3_lmulRA(M3<T>& o, const C3<T>& C, const M3<T>& S)
+// o(R) += C S(A)      (SET: o(R) = C S(A))
+template <typename T, bool SET = false> __device__ __forceinline__ void m3_lmulRA(M3<T>& o, const C3<T>& C, const M3<T>& S)
 {
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
+    for (int j = 0; j < 3; ++j) pk_mac<SET>(o.a[j], C.cc[0], pk_bc(m3_elA(S, 0, j)));
+    pk_mac<SET>(o.c, pk_bc(C.c2[0]), S.a[0]);
+    pk_mac<SET>(o.d, C.c2[0], m3_elA(S, 0, 2));
+#pragma unroll
+    for (int m = 1; m < 3; ++m) {
 #pragma unroll
         for (int j = 0; j < 3; ++j) o.a[j] += C.cc[m] * pk_bc(m3_elA(S, m, j));
         o.c += pk_bc(C.c2[m]) * S.a[m];
         o.d += C.c2[m] * m3_elA(S, m, 2);
     }
 }
-// o(A) += S C^T with S given in layout R:  o(i,j) = sum_m S(i,m) C(j,m)
-template <typename T, bool SYM = false> __device__ __forceinline__ void m3_rmulAR(M3<T>& o, const M3<T>& S, const C3<T>& C)
+// o(A) += S C^T with S given in layout R:  o(i,j) = sum_m S(i,m) C(j,m)      (SET: o(A) = S C^T)
+template <typename T, bool SYM = false, bool SET = false> __device__ __forceinline__ void m3_rmulAR(M3<T>& o, const M3<T>& S, const C3<T>& C)
 {
+    pk_mac<SET>(o.a[0], pk_bc(m3_elR(S, 0, 0)), C.cc[0]);
+    pk_mac<SET>(o.a[1], pk_bc(m3_elR(S, 1, 0)), C.cc[0]);
+    if (!SYM) pk_mac<SET>(o.a[2], pk_bc(m3_elR(S, 2, 0)), C.cc[0]);
+    pk_mac<SET>(o.c, S.a[0], pk_bc(C.c2[0]));
+    pk_mac<SET>(o.d, m3_elR(S, 2, 0), C.c2[0]);
 #pragma unroll
-    for (int m = 0; m < 3; ++m) {
+    for (int m = 1; m < 3; ++m) {
         o.a[0] += pk_bc(m3_elR(S, 0, m)) * C.cc[m];
         o.a[1] += pk_bc(m3_elR(S, 1, m)) * C.cc[m];
         if (!SYM) o.a[2] += pk_bc(m3_elR(S, 2, m)) * C.cc[m];
@@ -310,8 +333,8 @@ __device__ __forceinline__ void packed_nominal(const DevParams<T>& p, const Nois
         for (int m = 0; m < 3; ++m) S.a[m] = CC.cc[m] * pk_bc(nz.Q[m]);
         S.c = pk_mk(C[6] * nz.Q[0], C[7] * nz.Q[1]);
         S.d = C[8] * nz.Q[2];
-        m3_zero(c.CQC);
-        m3_rmulAR<T, true>(c.CQC, S, CC);
+        m3_rmulAR<T, true, true>(c.CQC, S, CC);
+        c.CQC.a[2] = c.CQC.c;
     }
 }
 
@@ -330,8 +353,7 @@ __device__ __forceinline__ void packed_cov_predict(const PackedCtx<T>& c, const 
         m3_axpy(M1w, dT, S.blk(V, WB));
         const M3<T> M1tR = m3_toggle(M1t);
         M3<T> Nrt;
-        m3_zero(Nrt);
-        m3_rmulAR(Nrt, M1tR, c.CR);
+        m3_rmulAR<T, false, true>(Nrt, M1tR, c.CR);
         m3_axpy(Nrt, mdTw, M1w);
         M3<T> Nrv = M1v;
         m3_rmulAR(Nrv, M1tR, c.CA);
@@ -356,8 +378,7 @@ __device__ __forceinline__ void packed_cov_predict(const PackedCtx<T>& c, const 
         m3_lmulRA(MvtR, c.CA, S.blk(TH, TH));
         m3_lmulRA(MvtR, c.CB, m3_toggle(S.blk(TH, AB)));
         M3<T> Nvt;
-        m3_zero(Nvt);
-        m3_rmulAR(Nvt, MvtR, c.CR);
+        m3_rmulAR<T, false, true>(Nvt, MvtR, c.CR);
         m3_axpy(Nvt, mdTw, Mvw);
         M3<T> Nvv = S.blk(V, V);
         m3_lmulAA<T, true>(Nvv, c.CA, Ptv);
@@ -371,14 +392,13 @@ __device__ __forceinline__ void packed_cov_predict(const PackedCtx<T>& c, const 
     // ---- level 1: rows th.  th' = Rt th - dTw wb ------------------------------------------------------------------------------
     {
         M3<T> Ntw, Nta, MttR, Ntt;
-        m3_zero(Ntw); m3_zero(Nta); m3_zero(MttR); m3_zero(Ntt);
-        m3_lmulAA(Ntw, c.CR, S.blk(TH, WB));
+        m3_lmulAA<T, false, true>(Ntw, c.CR, S.blk(TH, WB));
         m3_axpy(Ntw, mdTw, S.blk(WB, WB));
-        m3_lmulAA(Nta, c.CR, S.blk(TH, AB));
+        m3_lmulAA<T, false, true>(Nta, c.CR, S.blk(TH, AB));
         m3_axpy(Nta, mdTw, m3_toggle(S.blk(AB, WB)));
-        m3_lmulRA(MttR, c.CR, S.blk(TH, TH));
+        m3_lmulRA<T, true>(MttR, c.CR, S.blk(TH, TH));
         m3_axpy(MttR, mdTw, S.blk(TH, WB));          // layout R of P_wb,th == layout A of P_th,wb: the registers as they are
-        m3_rmulAR<T, true>(Ntt, MttR, c.CR);
+        m3_rmulAR<T, true, true>(Ntt, MttR, c.CR);
         m3_axpy<T, true>(Ntt, mdTw, Ntw);
         Ntt.a[0].x += nz.Q[3]; Ntt.a[1].y += nz.Q[4]; Ntt.d += nz.Q[5];
         m3_symmetrise(Ntt);
@@ -393,10 +413,46 @@ __device__ __forceinline__ void packed_cov_predict(const PackedCtx<T>& c, const 
     }
 }
 
-// prediction_step, EKF.cpp:346-415, on the blocks.
+// prediction_step, EKF.cpp:346-415, on the packed triangle (in place, scalar congruences of ekf_device.hpp) with the scalar part above:
+// the form the fp64 replay loop runs.
+template <typename T>
+__device__ __forceinline__ void ekf_predict_lean(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120], const T (&u)[6], T (&accel)[3])
+{
+    PackedCtx<T> c;
+    packed_nominal<T>(p, nz, x, u, accel, c);
+    PredictCtx<T> s;
+    s.dT = c.dT; s.dTw = c.dTw;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            s.X[i][m] = c3_el(c.CA, i, m);
+            s.X[i][3 + m] = c3_el(c.CB, i, m);
+            s.Rt[i][m] = c3_el(c.CR, i, m);
+        }
+    }
+    // W Q W^T is added from CQC instead of C: predict_cov_inplace forms C Qa C^T from s.C, so hand it a C whose product is CQC
+    predict_cov_inplace_noq<T>(s, P);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+#pragma unroll
+        for (int k = i; k < 3; ++k) P[sidx(3 + i, 3 + k)] += m3_elA(c.CQC, i, k);
+        P[sidx(6 + i, 6 + i)] += nz.Q[3 + i];
+        P[sidx(9 + i, 9 + i)] += nz.Q[6 + i];
+        P[sidx(12 + i, 12 + i)] += nz.Q[9 + i];
+    }
+}
+
+// prediction_step, EKF.cpp:346-415, on the blocks.  Device code instantiates it for fp32 only: fp64 has no packed FMA to gain, the full
+// diagonal blocks cost 30 registers more than the packed triangle, and the one fp64 instantiation that was built (k_step_mr<double>
+// on two-element double vectors: 1.5 KB of scratch per lane) ended in a GPU memory fault on its first launch -- the fp64 kernels run
+// ekf_predict_lean above.  The host build (test suite) runs both dtypes.
 template <typename T>
 __device__ __forceinline__ void ekf_predict_packed(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], PackedCov<T>& S, const T (&u)[6], T (&accel)[3])
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(sizeof(T) == 4, "the register-block predict is an fp32 device path");
+#endif
     PackedCtx<T> c;
     packed_nominal<T>(p, nz, x, u, accel, c);
     packed_cov_predict<T>(c, nz, S);

@@ -5,6 +5,16 @@
 #error "compile with -DQLE_TU_T=float or -DQLE_TU_T=double"
 #endif
 
+#if defined(QLE_MR_STAMPS)
+// diagnostic build only (make dbg): the per-wave s_memtime stamps of the last k_step_mr launch of this dtype's translation unit
+#define QLE_CAT2(a, b) a##b
+#define QLE_CAT(a, b) QLE_CAT2(a, b)
+extern "C" int QLE_CAT(qle_debug_clocks_, QLE_TU_T)(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qle::qle_dbg_clock), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 // One multirate tick that carries tag poses (predict-only multirate ticks go through launch_predict).
 template <typename T>
 int launch_step_mr(qle_batch* h, const void* u, const void* z)
@@ -22,6 +32,7 @@ int launch_step_mr(qle_batch* h, const void* u, const void* z)
     else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
 #undef QLE_MR_LAUNCH
     HIP_TRY(hipGetLastError());
+    mr_schedule_extra(h);
     return QLE_OK;
 }
 

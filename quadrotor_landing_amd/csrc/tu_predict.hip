@@ -17,7 +17,7 @@ int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, b
     const T* pfp = (const T*)h->pfp;
     // multirate history of this tick: the IMU sample's ring slot and, on checkpoint ticks, the checkpoint slot
     T* hu = history ? (T*)mr_u_slot_host(h, h->tick) : (T*)nullptr;
-    T* hc = history ? (T*)mr_ck_slot_host(h, h->tick) : (T*)nullptr;
+    T* hc = history ? (T*)mr_ck_for_predict(h, h->tick) : (T*)nullptr;
 #define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, h->B, h->split)
 #define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
     const int nt = effective_nt(h);
