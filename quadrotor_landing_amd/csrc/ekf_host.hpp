@@ -91,7 +91,7 @@ struct qle_batch {
     void* mr_u = nullptr;          // IMU ring: mr_Cu slots of kHW words per filter
     void* mr_ckpt = nullptr;       // state checkpoints: mr_Nc slots, one per mr_k ticks
     void* mr_anchor = nullptr;     // one state slot: every filter's corrected entry at hist_first
-    int32_t mr_k = 16, mr_Nc = 0, mr_Cu = 0;
+    int32_t mr_k = 32, mr_Nc = 0, mr_Cu = 0;
     // the extra checkpoint (slot mr_Nc), placed at the expected entry of the next measurement (k_step_mr, ekf_kernels.hpp)
     int64_t e_tick = -1;           // tick whose state the slot holds, -1 = none
     int64_t e_want = -1;           // the predict launch of this tick fills it, -1 = none scheduled

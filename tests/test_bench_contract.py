@@ -65,9 +65,9 @@ def test_bench_json_contract(extra):
         hr = d["hbm_resident"]
         assert 0 < hr["hbm_share"] < 1 and abs(hr["hbm_frac"] - hr["hbm_share"] * hr["achieved"] / 8000.0) < 1e-12
         assert rf["hbm_frac"] == hr["hbm_frac"] if rf["bound"] != "hbm" else rf["hbm_frac"] == rf["frac"]
+        assert d["f64_same_batch"]["dtype"] == "f64" and d["f64_same_batch"]["batch"] == 4096
     if "rmse_vs_truth" in d:
         assert d["rmse_vs_truth"]["wraps_in_timed_regions"] >= 0 and d["rmse_vs_truth"]["ticks"] == d["config"]["ticks_resident_in_hbm"]
-        assert d["f64_same_batch"]["dtype"] == "f64" and d["f64_same_batch"]["batch"] == 4096
     if not extra:
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
