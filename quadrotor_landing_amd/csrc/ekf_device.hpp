@@ -144,6 +144,62 @@ struct Noise {
     T R[6];
 };
 
+// sin(h) / (2 h) and cos(h): the vector scale and the scalar part of exp(phi), h = |phi| / 2 (QH.cpp:9-28).  Series in h^2 on
+// |h| <= pi/4 (truncation < 3e-10 in fp32, < 3e-20 in fp64); beyond, the library functions behind a branch no physical rate takes.
+template <typename T>
+__device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
+{
+    if (__builtin_expect(h2 > T(0.6168502750680849), 0)) {   // (pi/4)^2
+        const T h = t_sqrt(h2);
+        T s;
+        t_sincos(h, &s, &ch);
+        k = T(0.5) * s / h;
+        return;
+    }
+    if (sizeof(T) == 4) {
+        // sin h / h = 1 - h2/6 + h2^2/120 - h2^3/5040 + h2^4/362880 - h2^5/39916800
+        T s = T(-2.505210838544172e-08);
+        s = s * h2 + T(2.755731922398589e-06);
+        s = s * h2 + T(-1.984126984126984e-04);
+        s = s * h2 + T(8.333333333333333e-03);
+        s = s * h2 + T(-1.666666666666667e-01);
+        s = s * h2 + T(1);
+        k = T(0.5) * s;
+        T c = T(2.08767569878681e-09);
+        c = c * h2 + T(-2.755731922398589e-07);
+        c = c * h2 + T(2.48015873015873e-05);
+        c = c * h2 + T(-1.388888888888889e-03);
+        c = c * h2 + T(4.166666666666666e-02);
+        c = c * h2 + T(-0.5);
+        ch = c * h2 + T(1);
+    } else {
+        // 1/(2n+1)! and 1/(2n)! down to n = 10
+        T s = T(1.957294106339126e-20);
+        s = s * h2 + T(-8.22063524662433e-18);
+        s = s * h2 + T(2.811457254345521e-15);
+        s = s * h2 + T(-7.647163731819816e-13);
+        s = s * h2 + T(1.605904383682161e-10);
+        s = s * h2 + T(-2.505210838544172e-08);
+        s = s * h2 + T(2.755731922398589e-06);
+        s = s * h2 + T(-1.984126984126984e-04);
+        s = s * h2 + T(8.333333333333333e-03);
+        s = s * h2 + T(-1.666666666666667e-01);
+        s = s * h2 + T(1);
+        k = T(0.5) * s;
+        T c = T(4.110317623312165e-19);
+        c = c * h2 + T(-1.561920696858623e-16);
+        c = c * h2 + T(4.779477332387385e-14);
+        c = c * h2 + T(-1.147074559772972e-11);
+        c = c * h2 + T(2.08767569878681e-09);
+        c = c * h2 + T(-2.755731922398589e-07);
+        c = c * h2 + T(2.48015873015873e-05);
+        c = c * h2 + T(-1.388888888888889e-03);
+        c = c * h2 + T(4.166666666666666e-02);
+        c = c * h2 + T(-0.5);
+        ch = c * h2 + T(1);
+    }
+}
+
 // ------------------------------------------------------ quaternion helpers
 // quaternion_norm, QH.cpp:61-73: normalise, then flip to the w >= -0.75 cover.
 template <typename T>
@@ -156,14 +212,14 @@ __device__ __forceinline__ void quat_norm(T (&q)[4])
 }
 
 // quaternion_exp, QH.cpp:9-33 (including the final quaternion_norm at :30).
+// sin(|v|/2)/|v| and cos(|v|/2) come from half_angle_sinc_cos: the series the reference's small-angle branch truncates (QH.cpp:19-24),
+// valid for every |v| <= pi/2 without a square root, a division or a branch; larger arguments take the library path inside it.
 template <typename T>
 __device__ __forceinline__ void quat_exp(const T (&v)[3], T (&q)[4])
 {
-    T n = t_sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
-    T sh, ch;
-    t_sincos(n * T(0.5), &sh, &ch);
-    bool small = n < T(1E-10);
-    T k = small ? T(0.5) * (T(1) - n * n * (T(1) / T(24))) : sh / (small ? T(1) : n);
+    const T n2 = v[0] * v[0] + v[1] * v[1] + v[2] * v[2];
+    T k, ch;
+    half_angle_sinc_cos(T(0.25) * n2, k, ch);
     q[0] = v[0] * k; q[1] = v[1] * k; q[2] = v[2] * k; q[3] = ch;
     quat_norm(q);
 }
@@ -215,6 +271,62 @@ struct PredictCtx {
     T Rt[3][3];      // F[th,th], EKF.cpp:383-395
     T dT, dTw;
 };
+
+// Nominal state and the blocks of F in ONE pass without a transcendental call (used by every predict of the engine).
+// exp(phi) is needed for the nominal state anyway (EKF.cpp:367); F[th,th] = AngleAxis(-|phi|, phi/|phi|) (EKF.cpp:383-395) is the
+// rotation matrix of its conjugate, so the second sine / cosine (of the whole angle) and the normalised axis are not needed, and the
+// half-angle pair comes from half_angle_sinc_cos: no libm slow-path branch splits the block, the scheduler can interleave the chain with
+// the covariance work next to it.  The small-angle branches of the reference (QH.cpp:19-28, EKF.cpp:385-389) are the same series
+// truncated (agreement 1e-20).
+template <typename T>
+__device__ __forceinline__ void predict_nominal_lean(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], const T (&u)[6], T (&accel)[3],
+                                                     PredictCtx<T>& c)
+{
+    const T dT = p.dT;
+    c.dT = dT; c.dTw = p.dTw;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        c.a[i] = u[i] - x[10 + i] - nz.ab_static[i];                   // EKF.cpp:357
+        c.dw[i] = dT * (u[3 + i] - x[13 + i] - nz.wb_static[i]);       // EKF.cpp:358, :367
+    }
+    const T q[4] = {x[6], x[7], x[8], x[9]};
+    quat_to_rot(q, c.C);                                               // EKF.cpp:359
+#pragma unroll
+    for (int i = 0; i < 3; ++i) accel[i] = (c.C[3 * i] * c.a[0] + c.C[3 * i + 1] * c.a[1] + c.C[3 * i + 2] * c.a[2]) + p.g[i];   // EKF.cpp:362
+    const T n2 = c.dw[0] * c.dw[0] + c.dw[1] * c.dw[1] + c.dw[2] * c.dw[2];
+    T k, ch;
+    half_angle_sinc_cos(T(0.25) * n2, k, ch);                          // QH.cpp:9-28
+    T qe[4] = {c.dw[0] * k, c.dw[1] * k, c.dw[2] * k, ch};
+    quat_norm(qe);                                                     // QH.cpp:30
+    T qn[4];
+    quat_mul(q, qe, qn);                                               // EKF.cpp:367
+    quat_norm(qn);                                                     // EKF.cpp:371
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        x[i] += dT * x[3 + i];                                         // EKF.cpp:365
+        x[3 + i] += dT * accel[i];                                     // EKF.cpp:366
+    }
+    x[6] = qn[0]; x[7] = qn[1]; x[8] = qn[2]; x[9] = qn[3];
+    {   // Rt = R(exp(phi))^T
+        T Re[9];
+        quat_to_rot(qe, Re);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) c.Rt[i][m] = Re[3 * m + i];
+        }
+    }
+    const T mdT = -dT, mdTb = -dT * p.bias_on;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T c0 = c.C[3 * i], c1 = c.C[3 * i + 1], c2 = c.C[3 * i + 2];
+        c.X[i][0] = mdT * (c1 * c.a[2] - c2 * c.a[1]);                 // -dT C [a]x, EKF.cpp:381
+        c.X[i][1] = mdT * (c2 * c.a[0] - c0 * c.a[2]);
+        c.X[i][2] = mdT * (c0 * c.a[1] - c1 * c.a[0]);
+        c.X[i][3] = mdTb * c0; c.X[i][4] = mdTb * c1; c.X[i][5] = mdTb * c2;   // EKF.cpp:399
+    }
+}
+
 // Nominal state, EKF.cpp:356-371: x is advanced in place, accel = pose_accel (EKF.cpp:362).
 template <typename T>
 __device__ __forceinline__ void predict_nominal(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], const T (&u)[6], T (&accel)[3],
@@ -441,8 +553,7 @@ __device__ __forceinline__ void ekf_predict(const DevParams<T>& p, const Noise<T
                                             const T (&u)[6], T (&accel)[3])
 {
     PredictCtx<T> c;
-    predict_nominal<T>(p, nz, x, u, accel, c);
-    predict_jacobians<T>(p, c);
+    predict_nominal_lean<T>(p, nz, x, u, accel, c);
     predict_cov_inplace<T>(c, nz, P);
 }
 
@@ -574,9 +685,8 @@ __device__ __forceinline__ void ekf_predict_levels(const DevParams<T>& p, const 
                                                    const T (&u)[6], T (&accel)[3], T (&Pn)[120], Done done)
 {
     PredictCtx<T> c;
-    predict_nominal<T>(p, nz, x, u, accel, c);
+    predict_nominal_lean<T>(p, nz, x, u, accel, c);
     done(-1);  // x is final
-    predict_jacobians<T>(p, c);
     predict_level0<T>(nz, P, Pn);
     done(0);
     predict_level1<T>(c, nz, P, Pn);

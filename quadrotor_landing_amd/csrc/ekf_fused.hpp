@@ -70,7 +70,7 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
     PredictCtx<T> c;
     {
         T accel[3];
-        predict_nominal<T>(p, nzl, x, u, accel, c);
+        predict_nominal_lean<T>(p, nzl, x, u, accel, c);
         emit_accel(accel);
     }
     // correction, the parts that need only the predicted nominal state
@@ -80,7 +80,6 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
     quad::FactorIn<T> in;
 #pragma unroll
     for (int k = 0; k < 6; ++k) in.dy_[k] = T(0);   // the factor below is wanted for L and D only; dy is eliminated after the sweep
-    predict_jacobians<T>(p, c);
     quad::update_noise<SQ, T, DIRECT>(p, nz, x, in.gx, in.rk);
     // the rows S is read from
     predict_level3<T>(c, Po, Pn);

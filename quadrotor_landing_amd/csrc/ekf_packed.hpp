@@ -203,62 +203,6 @@ __device__ __forceinline__ void cov_unpack(const PackedCov<T>& S, T (&P)[120])
     }
 }
 
-// sin(h) / (2 h) and cos(h): the vector scale and the scalar part of exp(phi), h = |phi| / 2 (QH.cpp:9-28).  Series in h^2 on
-// |h| <= pi/4 (truncation < 3e-10 in fp32, < 3e-20 in fp64); beyond, the library functions behind a branch no physical rate takes.
-template <typename T>
-__device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
-{
-    if (__builtin_expect(h2 > T(0.6168502750680849), 0)) {   // (pi/4)^2
-        const T h = t_sqrt(h2);
-        T s;
-        t_sincos(h, &s, &ch);
-        k = T(0.5) * s / h;
-        return;
-    }
-    if (sizeof(T) == 4) {
-        // sin h / h = 1 - h2/6 + h2^2/120 - h2^3/5040 + h2^4/362880 - h2^5/39916800
-        T s = T(-2.505210838544172e-08);
-        s = s * h2 + T(2.755731922398589e-06);
-        s = s * h2 + T(-1.984126984126984e-04);
-        s = s * h2 + T(8.333333333333333e-03);
-        s = s * h2 + T(-1.666666666666667e-01);
-        s = s * h2 + T(1);
-        k = T(0.5) * s;
-        T c = T(2.08767569878681e-09);
-        c = c * h2 + T(-2.755731922398589e-07);
-        c = c * h2 + T(2.48015873015873e-05);
-        c = c * h2 + T(-1.388888888888889e-03);
-        c = c * h2 + T(4.166666666666666e-02);
-        c = c * h2 + T(-0.5);
-        ch = c * h2 + T(1);
-    } else {
-        // 1/(2n+1)! and 1/(2n)! down to n = 10
-        T s = T(1.957294106339126e-20);
-        s = s * h2 + T(-8.22063524662433e-18);
-        s = s * h2 + T(2.811457254345521e-15);
-        s = s * h2 + T(-7.647163731819816e-13);
-        s = s * h2 + T(1.605904383682161e-10);
-        s = s * h2 + T(-2.505210838544172e-08);
-        s = s * h2 + T(2.755731922398589e-06);
-        s = s * h2 + T(-1.984126984126984e-04);
-        s = s * h2 + T(8.333333333333333e-03);
-        s = s * h2 + T(-1.666666666666667e-01);
-        s = s * h2 + T(1);
-        k = T(0.5) * s;
-        T c = T(4.110317623312165e-19);
-        c = c * h2 + T(-1.561920696858623e-16);
-        c = c * h2 + T(4.779477332387385e-14);
-        c = c * h2 + T(-1.147074559772972e-11);
-        c = c * h2 + T(2.08767569878681e-09);
-        c = c * h2 + T(-2.755731922398589e-07);
-        c = c * h2 + T(2.48015873015873e-05);
-        c = c * h2 + T(-1.388888888888889e-03);
-        c = c * h2 + T(4.166666666666666e-02);
-        c = c * h2 + T(-0.5);
-        ch = c * h2 + T(1);
-    }
-}
-
 // What one predicted tick needs besides P: the blocks of F that are not identity, as coefficient matrices, and C Qa C^T.
 template <typename T>
 struct PackedCtx {

@@ -50,7 +50,13 @@ struct ScalarQ {
     static __host__ __device__ __forceinline__ V sqrt(V v) { return t_sqrt(v); }
     static __host__ __device__ __forceinline__ V atan2(V a, V b) { return t_atan2(a, b); }
     static __host__ __device__ __forceinline__ void sincos(V v, V* s, V* c) { t_sincos(v, s, c); }
+    // one plain value per instance: the polynomial half-angle pair of ekf_device.hpp applies (no libm call on the chain)
+    static constexpr bool kLean = true;
+    static __host__ __device__ __forceinline__ void half_angle(V h2, V& k, V& ch) { half_angle_sinc_cos(h2, k, ch); }
 };
+// `Q::kLean` for contexts that do not say: the general (library call + selects) forms below
+template <class Q, typename = void> struct QLean { static constexpr bool value = false; };
+template <class Q> struct QLean<Q, decltype((void)Q::kLean)> { static constexpr bool value = Q::kLean; };
 
 #if defined(__HIPCC__) || defined(__HIP_DEVICE_COMPILE__)
 template <int CTRL>
@@ -130,6 +136,13 @@ template <class Q>
 __host__ __device__ __forceinline__ void q_exp(const typename Q::V (&v)[3], typename Q::V (&q)[4])   // QH.cpp:9-33
 {
     using V = typename Q::V;
+    if constexpr (QLean<Q>::value) {   // the same series the small-angle branch truncates, valid up to |v| = pi/2 (ekf_device.hpp)
+        V k, ch;
+        Q::half_angle(V(0.25) * (v[0] * v[0] + v[1] * v[1] + v[2] * v[2]), k, ch);
+        q[0] = v[0] * k; q[1] = v[1] * k; q[2] = v[2] * k; q[3] = ch;
+        q_norm<Q>(q);
+        return;
+    }
     V n = Q::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
     V sh, ch;
     Q::sincos(n * V(0.5), &sh, &ch);
@@ -248,8 +261,9 @@ __host__ __device__ __forceinline__ void predict_scalar(const DevParams<T>& p, c
 #pragma unroll
     for (int i = 0; i < 3; ++i) accel[i] = (C[3 * i] * a[0] + C[3 * i + 1] * a[1] + C[3 * i + 2] * a[2]) + V(p.g[i]);  // EKF.cpp:362
     V dw[3] = {dT * w[0], dT * w[1], dT * w[2]};
+    V qe[4];
     {
-        V qe[4], qn[4];
+        V qn[4];
         q_exp<Q>(dw, qe);
         q_mul(q, qe, qn);
         q_norm<Q>(qn);
@@ -269,7 +283,15 @@ __host__ __device__ __forceinline__ void predict_scalar(const DevParams<T>& p, c
         o.A[3 * i + 2] = mdT * (c0 * a[1] - c1 * a[0]);
         o.Bm[3 * i] = mdTb * c0; o.Bm[3 * i + 1] = mdTb * c1; o.Bm[3 * i + 2] = mdTb * c2;
     }
-    {
+    if constexpr (QLean<Q>::value) {   // F[th,th] = R(exp(phi))^T (EKF.cpp:383-395): no second sine / cosine, no axis, no selects
+        V Re[9];
+        q_to_rot(qe, Re);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+#pragma unroll
+            for (int m = 0; m < 3; ++m) o.Rt[3 * i + m] = Re[3 * m + i];
+        }
+    } else {
         V ang = Q::sqrt(dw[0] * dw[0] + dw[1] * dw[1] + dw[2] * dw[2]);
         const typename Q::M small = Q::lt(ang, V(p.small_ang_tol));
         V inv = V(1) / Q::sel(small, V(1), ang);
