@@ -243,7 +243,8 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // (32 768 filters: fp32 13.0 vs 12.0 us, fp64 28.2 vs 25.5; 65 536: 25 vs 14.7 and 60 vs 38), so it is selected only there and
     // only for ticks with tag poses (predict-only ticks take the same time on both).  QLE_QUAD=bits overrides (1: ticks with tag
     // poses, 2: predict-only ticks, 0: never).
-    h->quad = batch <= 16384 ? 1 : 0;
+    // up to 4 096 filters (quarter-tile workgroups, one per CU) it also takes the predict-only ticks: 6.3 against 7.75 us at 4 096 fp64
+    h->quad = batch <= 4096 ? 3 : (batch <= 16384 ? 1 : 0);
     if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
     // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
     // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16

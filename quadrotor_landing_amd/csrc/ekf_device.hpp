@@ -904,7 +904,6 @@ __device__ __forceinline__ void ekf_update_emit(const DevParams<T>& p, const Noi
     ekf_update_prepare<T, DIRECT>(p, nz, x, z, u, emit_obs);
     ekf_update_apply<T, DIRECT>(p, x, P, u);
 }
-
 template <typename T, bool DIRECT>
 __device__ __forceinline__ void ekf_update(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120],
                                            const T (&z)[7], T (&obs)[7])

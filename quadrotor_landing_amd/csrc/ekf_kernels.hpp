@@ -501,8 +501,16 @@ static __device__ unsigned long long qle_dbg_clock[kDbgWaves * kDbgSlots];
         asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                              \
         if ((i & 63) == 0 && (i >> 6) < kDbgWaves && (k) < kDbgSlots) qle_dbg_clock[(i >> 6) * kDbgSlots + (k)] = t_;       \
     } while (0)
+// the same for a kernel that names its wave and its writing lane itself (kw_tick: one workgroup per tile)
+#define QLE_STAMPW(wave, writer, k, dep)                                                                                   \
+    do {                                                                                                                   \
+        unsigned long long t_;                                                                                             \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                              \
+        if ((writer) && (wave) < kDbgWaves && (k) < kDbgSlots) qle_dbg_clock[(wave) * kDbgSlots + (k)] = t_;                \
+    } while (0)
 #else
 #define QLE_STAMP(k, dep) do { } while (0)
+#define QLE_STAMPW(wave, writer, k, dep) do { } while (0)
 #endif
 
 // Minimum of a value over the 64 lanes of the wave, as a wave-uniform (SGPR) value.  Every lane must be active.
@@ -638,21 +646,37 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     // covers the latency of the ring, which was streamed to HBM; requesting the whole window up front instead (LDS-DMA into a per-wave LDS
     // window, profiles/r03_tuning.md) made the loop 4 % shorter and the prologue 15 000 cycles longer: the requests of all waves arrive
     // at once and queue behind one another.
+    // The current tick's own sample joins the same chain of one-ahead requests (it is asked for again while the last replayed tick is
+    // computed) so that it is not carried in registers through the whole replay.
     T un[kHW];
     if (t_lo + 1 < m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t_lo + 1), i, un);
+    else {
+#pragma unroll
+        for (int k = 0; k < kUW; ++k) un[k] = u[k];
+    }
     int dbg_j = 0;
     (void)dbg_j;
     for (int32_t t = t_lo;;) {                 // t is wave-uniform
         if (corr && t == mt) {                                // the entry the measurement belongs to
             QLE_STAMP(5, x[0]);
-            const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+            T z[7];
+            if constexpr (sizeof(T) == 8) {   // fp64: the tag pose is read again here instead of occupying 16 registers through the pre-replay
+                T zq[kZW];
+                load_rec<T, kZW, 0, kZW>(zs, i, zq);
+#pragma unroll
+                for (int k = 0; k < 7; ++k) z[k] = zq[k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) z[k] = zr[k];
+            }
             S.template with_flat<true>([&](T (&P)[kPW]) {
-                ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [&](const T (&o)[7]) {   // EKF.cpp:209
+                auto emit = [&](const T (&o)[7]) {                // EKF.cpp:209
                     if (aux_accel) {
 #pragma unroll
                         for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
                     }
-                });
+                };
+                ekf_update_emit<T, DIRECT>(p, nz, x, P, z, emit);
                 store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
                 store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
             });
@@ -663,9 +687,15 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         const bool now = t == m.tick;                         // wave-uniform
         T u6[kUW];
 #pragma unroll
-        for (int k = 0; k < kUW; ++k) u6[k] = now ? u[k] : un[k];   // `now` is wave-uniform: a scalar select
+        for (int k = 0; k < kUW; ++k) u6[k] = un[k];
         QLE_STAMP(8 + 2 * dbg_j, u6[0] + u6[5]);
         if (t + 1 < m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t + 1), i, un);
+        else if (t + 1 == m.tick) {
+            T uc[kUW];
+            load_rec<T, kUW, 0, kUW>(us, i, uc);
+#pragma unroll
+            for (int k = 0; k < kUW; ++k) un[k] = uc[k];
+        }
         if (valid && t > start) {
             S.predict(p, nz, x, u6, accel);
             QLE_STAMP(9 + 2 * dbg_j, x[0] + x[9] + S.probe());
@@ -676,7 +706,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
                     if (now) {
                         store_rec<T, kSW, 0, kXW>(cur, i, x);
                         store_rec<T, kSW, kXW, kPW>(cur, i, P);
-                        const T uk[kHW] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
+                        const T uk[kHW] = {u6[0], u6[1], u6[2], u6[3], u6[4], u6[5], T(0), T(0)};
                         store_rec<T, kHW, 0, kHW, 2>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
                     }
                     if (ck) {

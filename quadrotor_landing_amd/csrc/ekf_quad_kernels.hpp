@@ -114,21 +114,50 @@ template <typename T> struct WgWaves { static constexpr int value = sizeof(T) ==
 // One tick of tile `tile` by its workgroup: predict, and with STEP correct where the tag record's mask word is set (GATE:
 // where filter_update's decision logic says so, EKF.cpp:147-186).  In place on `st`.  A filter whose stored quaternion is
 // all zero has not been initialised (EKF.cpp:129-130) and is left untouched.
-template <typename T, bool DIRECT, bool PFP, bool GATE, bool STEP, int NT>
+// FPW = filters per workgroup.  64: the workgroup is one whole tile, wave 0 carries the main scalar role next to its quads, waves 1 and 2
+// the helper roles.  16: the workgroup is a QUARTER of a tile (filters f0 .. f0+15 of it) -- wave 0 holds the 16 quads, lanes 0..15 of
+// waves 1, 2, 3 the main scalar role and the two helper roles -- so that a batch of a few thousand filters spreads over all 256 CUs
+// instead of 64: the tick of such a batch is bound by what ONE CU can load and store (a tile's 60 KiB of fp64 covariance each way at
+// ~11 bytes per cycle: 8 400 + 5 400 of the 25 000 cycles of a tick at 4 096 fp64 filters, profiles/r03_tuning.md), not by the chip.
+template <typename T, bool DIRECT, bool PFP, bool GATE, bool STEP, int NT, int FPW>
 __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams& gp, T* st, const T* __restrict__ us, const T* __restrict__ zs,
                                         const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                        int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int64_t tile, T* lds)
+                                        int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int64_t tile, int f0, T* lds)
 {
     using DQ = quad::DevQ<T>;
     using SQ = quad::ScalarQ<T>;
+    static_assert(FPW == 64 || FPW == 16, "a workgroup is a tile or a quarter of one");
     constexpr int NTL = NtLd<NT, kSW>::value, NTS = NtSt<NT>::value;
-    const int t = (int)threadIdx.x;
-    const bool scalar_wave = t < kTile;
-    const int fq = t >> 2, j = t & 3;
-    const bool in_q = tile * kTile + fq < B;
+    constexpr int SM = FPW == 64 ? 0 : 1;            // the wave of the main scalar role
+    const int t = (int)threadIdx.x, w = t >> 6, l = t & 63;
+    const bool scalar_wave = w == SM && l < FPW;
+    const int lfq = t >> 2, j = t & 3;               // quad role: local filter, lane of its quad
+    const int fq = f0 + lfq;                         // that filter's position in the tile
+    const bool quad_thread = t < 4 * FPW;
+    const bool in_q = quad_thread && tile * kTile + fq < B;
     T* tb = st + tile * (int64_t)(kSW * kTile);
 
-    // ---- covariance loads (quad role), issued first: the scalar phase below runs while they are in flight
+    // diagnostic build (make dbg): the first thread of the quad role / of the main scalar role stamps the phases
+    // (profiles/r03_scripts/kw_timeline.py)
+    const int dbg_id = (int)(tile * (kTile / FPW)) + f0 / FPW;
+    (void)dbg_id;
+#define QLE_KW_STAMP(k, dep) QLE_STAMPW(dbg_id, (((k) == 0 || (k) == 3 || (k) == 4 || (k) == 7 || (k) == 8) ? t == 0 : t == SM * 64), k, dep)
+    QLE_KW_STAMP(0, (T)t);
+    // ---- loads.  The records of the scalar roles (x, u, z: a few rows) are requested BEFORE the covariance: a wave's loads return in
+    // order, so with the covariance first the scalar chain waited for all 60 KiB of the tile (5 200 of the tick's 25 600 cycles at
+    // 4 096 fp64 filters, profiles/r03_tuning.md) instead of running while the covariance is in flight.
+    const int64_t js = tile * kTile + f0 + l;                          // the filter of this thread's scalar role (lane l of its wave)
+    const int64_t is = js;
+    T* mine = lds + l * kLdsStride;   // scalar roles: the record of local filter l
+    const bool helper_wave = STEP && (w == SM + 1 || w == SM + 2) && l < FPW;   // ticks with tag poses: the two waves after the main one
+    const bool helper_first = w == SM + 1;
+    T sx[kXW], su[kUW], szr[kZW], sfp[kFW];
+    if ((scalar_wave || helper_wave) && js < B) {
+        load_rec<T, kUW, 0, kUW, NT>(us, js, su);
+        load_rec<T, kSW, 0, kXW, NT>(st, js, sx);
+        if (STEP) load_rec<T, kZW, 0, kZW, NT>(zs, js, szr);
+        if (PFP) load_rec<T, kFW, 0, kFW, NT>(pfp, js, sfp);
+    }
     T L[quad::kList];
     if (in_q && j < 3) quad_load_P<T, 0, 10, NTL>(tb, fq, j, L);
     else {
@@ -137,20 +166,15 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
     }
 
     // ---- scalar role: nominal state, blocks of F, the decision whether this filter corrects
-    const int64_t is = tile * kTile + t;
-    T* mine = lds + t * kLdsStride;   // wave 0: the record of filter t
     if (scalar_wave) {
-        T x[kXW], zr[kZW];
+        T (&x)[kXW] = sx;
+        T (&zr)[kZW] = szr;
         quad::NoiseV<T> nz;
         bool live = false, corr = false;
         if (is < B) {
-            T u[kUW];
-            load_rec<T, kUW, 0, kUW, NT>(us, is, u);
-            load_rec<T, kSW, 0, kXW, NT>(st, is, x);
-            if (STEP) load_rec<T, kZW, 0, kZW, NT>(zs, is, zr);
+            T (&u)[kUW] = su;
             if (PFP) {
-                T fp[kFW];
-                load_rec<T, kFW, 0, kFW, NT>(pfp, is, fp);
+                T (&fp)[kFW] = sfp;
 #pragma unroll
                 for (int k = 0; k < 12; ++k) nz.Q[k] = fp[k];
 #pragma unroll
@@ -166,6 +190,7 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
                 for (int k = 0; k < 6; ++k) nz.R[k] = p.R[k];
             }
             live = !filter_uninitialised(x);
+            QLE_KW_STAMP(1, x[9] + u[5]);
             if (live) {
                 if (STEP) {
                     corr = zr[7] != T(0);
@@ -184,6 +209,7 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
                 quad::PredU<T> pu;
                 T accel[3];
                 quad::predict_scalar<SQ, T>(p, nz, x, u, accel, pu);
+                QLE_KW_STAMP(2, pu.Rt[8] + pu.A[0] + x[9]);
 #pragma unroll
                 for (int k = 0; k < 9; ++k) {
                     mine[kLdsU1 + k] = pu.A[k]; mine[kLdsU1 + 9 + k] = pu.Bm[k]; mine[kLdsU1 + 18 + k] = pu.Rt[k];
@@ -193,6 +219,7 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
 #pragma unroll
                     for (int k = 0; k < 3; ++k) aux_accel[is * 3 + k] = accel[k];
                 }
+                // (see the INVARIANT at the helper waves below: this early store is only for filters that do not correct)
                 if (!(STEP && corr)) store_rec<T, kSW, 0, kXW, NT>(st, is, x);
                 else {   // the predicted nominal state waits in LDS while the quads work (keeps the quad phases' register count down)
 #pragma unroll
@@ -201,20 +228,20 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
             }
         }
         mine[kLdsFlag] = T((live ? 1 : 0) | (corr ? 2 : 0));
-    } else if (STEP && t < 3 * kTile) {
-        // waves 1 and 2, filter t % 64: what the correction needs of the predicted NOMINAL state only, side by side with wave 0
-        const int fs = t & (kTile - 1);
-        const int64_t js = tile * kTile + fs;
-        T* rec_s = lds + fs * kLdsStride;
+    } else if (helper_wave) {
+        // waves 1 and 2, filter t % 64: what the correction needs of the predicted NOMINAL state only, side by side with wave 0.
+        // INVARIANT (no barrier orders these waves' load of x against wave 0's in-place store of the predicted x): wave 0 stores x
+        // early only for a filter that does NOT correct on this tick (gate refused, mask clear), and everything these waves write for
+        // such a filter -- dy, Gx, R_k, the reported observation in kLdsPre -- is read only where flag bit 1 (corrects) is set.  A torn
+        // or already-predicted x can therefore only produce values nobody reads; any new consumer of kLdsPre must keep to bit 1.
+        T* rec_s = mine;
         if (js < B) {
-            T x[kXW], u[kUW], zr[kZW];
-            load_rec<T, kUW, 0, kUW, NT>(us, js, u);
-            load_rec<T, kSW, 0, kXW, NT>(st, js, x);
-            load_rec<T, kZW, 0, kZW, NT>(zs, js, zr);
+            T (&x)[kXW] = sx;
+            T (&u)[kUW] = su;
+            T (&zr)[kZW] = szr;
             quad::NoiseV<T> nz;
             if (PFP) {
-                T fp[kFW];
-                load_rec<T, kFW, 0, kFW, NT>(pfp, js, fp);
+                T (&fp)[kFW] = sfp;
 #pragma unroll
                 for (int k = 0; k < 3; ++k) { nz.ab_static[k] = fp[12 + k]; nz.wb_static[k] = fp[15 + k]; }
 #pragma unroll
@@ -227,7 +254,7 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
             }
             if (!filter_uninitialised(x) && zr[7] != T(0)) {
                 quad::predict_nominal<SQ, T>(p, nz, x, u);
-                if (t < 2 * kTile) {
+                if (helper_first) {
                     const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
                     T dy[6];
                     quad::update_innovation<SQ, T, DIRECT>(p, x, z, dy, [&](const T (&obs)[7]) {
@@ -250,8 +277,9 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
     __syncthreads();
 
     // ---- quad role: P <- F P F^T + Q; the words of a block-row are stored as soon as they are final unless a correction follows
-    T* rec = lds + fq * kLdsStride;
+    T* rec = lds + (quad_thread ? lfq : 0) * kLdsStride;
     const int fl = (int)rec[kLdsFlag];
+    QLE_KW_STAMP(3, (T)fl + L[0] + L[39]);
     const bool live_q = in_q && (fl & 1) != 0, corr_q = STEP && (fl & 2) != 0;
     T Ln[quad::kList], Prr[3], Ptt[3];
     if (live_q) {
@@ -264,6 +292,7 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
             else quad_store_P<T, 0, 4, NTS>(tb, fq, j, Ln);
         });
     }
+    QLE_KW_STAMP(4, Ln[0] + Ln[39]);
     if (!STEP) return;
     if (live_q && corr_q && j < 3) {   // the blocks of the predicted P over {r, th}: column j of each
 #pragma unroll
@@ -277,9 +306,11 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
 
     // ---- scalar role: innovation, S = G P G^T + R_k = L D L^T
     const bool corr_s = scalar_wave && ((int)mine[kLdsFlag] & 2) != 0;
+    QLE_KW_STAMP(5, mine[kLdsFlag]);
     if (corr_s) {
         quad::UpdU<T> uu;
         quad::update_factor<SQ, DIRECT>(LdsFactorIn<T>{mine}, uu);
+        QLE_KW_STAMP(6, uu.invd[5] + uu.yd[5]);
         if (aux_accel) {
 #pragma unroll
             for (int k = 0; k < 7; ++k) aux_obs[is * 7 + k] = mine[kLdsPre + 36 + k];
@@ -296,19 +327,27 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
     __syncthreads();
 
     // ---- quad role: P <- P - V D^-1 V^T, rows of dx
+    QLE_KW_STAMP(7, rec[kLdsU1]);
     if (live_q && corr_q) {
         const LdsUpdQ<T, DIRECT> g{rec};
         T dxo[5];
         quad::update_P<DQ, DIRECT>(g, Ln, Prr, Ptt, dxo);
+        QLE_KW_STAMP(8, dxo[0] + dxo[4] + Ln[0] + Ln[39]);
         if (j < 3) {
 #pragma unroll
             for (int b = 0; b < 5; ++b) rec[kLdsU2 + 3 * b + j] = dxo[b];
             quad_store_P<T, 0, 10, NTS>(tb, fq, j, Ln);
         }
     }
-    __syncthreads();
+    // The injection needs dx from LDS and nothing from memory: a barrier that waits for the LDS writes only.  __syncthreads() also
+    // waits for every outstanding global access (s_waitcnt vmcnt(0)), i.e. for the drain of the 60 KiB of covariance stores just
+    // issued: 5 500 of the tick's 25 600 cycles at 4 096 fp64 filters before the last scalar phase could start.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
 
     // ---- scalar role: inject the error state (EKF.cpp:486-501)
+    QLE_KW_STAMP(9, mine[kLdsU2]);
     if (corr_s) {
         T x[kXW], dx[15];
 #pragma unroll
@@ -316,23 +355,30 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
 #pragma unroll
         for (int k = 0; k < 15; ++k) dx[k] = mine[kLdsU2 + k];
         quad::update_inject<SQ, T>(p, x, dx);
+        QLE_KW_STAMP(10, x[9] + x[0]);
         store_rec<T, kSW, 0, kXW, NT>(st, is, x);
     }
+    QLE_KW_STAMP(11, (T)t);
+#undef QLE_KW_STAMP
 }
 
-// Grid: one 256-thread workgroup per tile.  NT as in k_predict / k_step (3 = cached / streamed split per workgroup).
-template <typename T, bool DIRECT, bool PFP, bool GATE, bool STEP, int NT>
+// Grid: one 256-thread workgroup per FPW filters (a tile, or a quarter of one).  NT as in k_predict / k_step (3 = cached / streamed split
+// per workgroup).
+template <typename T, bool DIRECT, bool PFP, bool GATE, bool STEP, int NT, int FPW>
 __global__ __launch_bounds__(kBlock, WgWaves<T>::value) void kw_tick(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us, const T* __restrict__ zs,
                                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
                                                                       int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
 {
-    __shared__ T lds[kTile * kLdsStride];
-    const int64_t tile = batch_block();
+    __shared__ T lds[FPW * kLdsStride];
+    constexpr int PER = kTile / FPW;
+    const int64_t wg = batch_block();
+    const int64_t tile = wg / PER;
+    const int f0 = (int)(wg % PER) * FPW;
     if (NT == 3) {
-        if (cached_workgroup(split)) wg_tick<T, DIRECT, PFP, GATE, STEP, 0>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, B, tile, lds);
-        else wg_tick<T, DIRECT, PFP, GATE, STEP, 2>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, B, tile, lds);
+        if (cached_workgroup(split)) wg_tick<T, DIRECT, PFP, GATE, STEP, 0, FPW>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, B, tile, f0, lds);
+        else wg_tick<T, DIRECT, PFP, GATE, STEP, 2, FPW>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, B, tile, f0, lds);
     } else {
-        wg_tick<T, DIRECT, PFP, GATE, STEP, NT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, B, tile, lds);
+        wg_tick<T, DIRECT, PFP, GATE, STEP, NT, FPW>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, B, tile, f0, lds);
     }
 }
 
