@@ -11,6 +11,7 @@
 //
 //   ekf_driver --config relative_pose_EKF_rotors.yaml --batch 65536 --ticks 1000 [--dtype f32|f64]
 //              [--device 0] [--seed N] [--update-freq HZ] [--measurement-freq HZ] [--corner-gate 0|1] [--multirate 0|1]
+//              [--json]        print ONE JSON line with the fields of bench.py's line (value, ms_per_step, per-shard device times)
 //              [--devices N]   shard the batch over N devices in this process: one handle + one HIP stream per
 //                              device, one host thread each, no collective; the three RMSE sums and the reports
 //                              are combined on the host.  Shards wrap onto the devices
@@ -23,6 +24,7 @@
 //                              and FilterUpdateCallback fires every 1/update_freq s from the first event on.  Every
 //                              filter of the batch sees the same stream; --trace writes what the node would publish
 //                              for filter 0 on every tick (NODE.cpp:192-281).
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -216,6 +218,7 @@ int main(int argc, char** argv)
     uint64_t seed = 0xE4F00001ULL;
     double update_freq = 0, measurement_freq = 0;
     int corner_gate = -1, multirate = -1, n_devices = 1;
+    bool json = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         auto next = [&]() { if (i + 1 >= argc) { std::fprintf(stderr, "missing value for %s\n", a.c_str()); std::exit(2); } return std::string(argv[++i]); };
@@ -232,6 +235,7 @@ int main(int argc, char** argv)
         else if (a == "--corner-gate") corner_gate = std::atoi(next().c_str());
         else if (a == "--multirate") multirate = std::atoi(next().c_str());
         else if (a == "--devices") n_devices = std::max(1, std::atoi(next().c_str()));
+        else if (a == "--json") json = true;
         else { std::fprintf(stderr, "unknown argument %s\n", a.c_str()); return 2; }
     }
 
@@ -305,6 +309,13 @@ int main(int argc, char** argv)
     }
     std::vector<uint8_t> has((size_t)ticks, 0);
     for (int64_t t = d.upd_per_meas - 1; t < ticks; t += d.upd_per_meas) has[(size_t)t] = 1;  // a tag pose every upd_per_meas ticks
+    // every shard starts its timed ticks together: the threads meet here once their inputs are generated (a shard that failed on
+    // the way still arrives, so nobody waits for it)
+    std::atomic<int> arrived{0};
+    auto meet = [&]() {
+        arrived.fetch_add(1);
+        while (arrived.load() < n_devices) std::this_thread::yield();
+    };
     auto run_shard = [&](Shard& sh) {
         // errors are thread-local in the library: report them through the shard
         auto ok = [&](int rc, const char* what) {
@@ -313,7 +324,8 @@ int main(int argc, char** argv)
         };
         qle_batch* h = nullptr;
         qle_inputs* in = nullptr;
-        if (sh.n == 0) return;
+        bool met = false;
+        if (sh.n == 0) { meet(); return; }
         do {
             if (!ok(qle_create(&h, sh.n, dtype, sh.dev, &p), "qle_create")) break;
             if (!ok(qle_enable_gating(h, 1), "qle_enable_gating")) break;
@@ -330,6 +342,7 @@ int main(int argc, char** argv)
             }
             if (!ok(qle_synth_generate(h, in, &sc), "qle_synth_generate")) break;
             if (!ok(qle_synchronize(h), "qle_synchronize")) break;
+            meet(); met = true;
             if (!ok(qle_timer_begin(h), "qle_timer_begin")) break;
             if (!ok(qle_run(h, in, 0, ticks), "qle_run")) break;
             if (!ok(qle_timer_end(h, &sh.ms), "qle_timer_end")) break;
@@ -342,6 +355,7 @@ int main(int argc, char** argv)
             if (!ok(qle_count_nonfinite(h, &sh.bad), "qle_count_nonfinite")) break;
             for (int64_t i = 0; i < sh.n; ++i) sh.tracked += sh.upds[(size_t)i] < 2 * d.upd_per_meas ? 1 : 0;
         } while (false);
+        if (!met) meet();
         qle_inputs_destroy(in);
         qle_destroy(h);
     };
@@ -368,6 +382,24 @@ int main(int argc, char** argv)
     const std::vector<double>&pose = shards[0].pose, &cov = shards[0].cov, &vel = shards[0].vel, &bias = shards[0].bias;
     const std::vector<int32_t>& upds = shards[0].upds;
 
+    if (json) {
+        // the fields of bench.py's line for the in-process sharding (one handle + stream + host thread per device, no torchrun): a fixed
+        // population split over the devices (strong scaling), device time = max over the shards' HIP-event times of the same ticks
+        std::printf("{\"metric\": \"EKF predict+update steps/sec; in-process sharding over devices\", \"value\": %.6e, \"unit\": \"EKF ticks/s\", "
+                    "\"n_gpus\": %d, \"devices_present\": %d, \"steps\": %lld, \"warmup\": 0, \"ms_per_step\": %.6f, \"higher_is_better\": true, "
+                    "\"scaling\": \"strong\", \"vs_baseline\": null, \"dtype\": \"%s\", \"data\": \"synthetic\", "
+                    "\"config\": {\"workload\": \"ekf_driver: %lld filters x %lld ticks, tag pose every %d ticks, multirate %d\", \"global_batch\": %lld, "
+                    "\"parallelism\": \"filters sharded x%d in one process, no collectives\"}, \"per_shard\": [",
+                    (double)batch * ticks / (ms * 1e-3), n_devices, (int)ndev_avail, (long long)ticks, ms / (double)ticks, dtype == QLE_F32 ? "f32" : "f64",
+                    (long long)batch, (long long)ticks, d.upd_per_meas, p.multirate_ekf, (long long)batch, n_devices);
+        for (size_t k = 0; k < shards.size(); ++k)
+            std::printf("%s{\"device\": %d, \"filter_offset\": %lld, \"filters\": %lld, \"hip_event_ms\": %.4f}", k ? ", " : "", shards[k].dev,
+                        (long long)shards[k].lo, (long long)shards[k].n, shards[k].ms);
+        std::printf("], \"wall_ms_incl_setup\": %.3f, \"rmse_vs_truth\": {\"position_m\": %.6f, \"attitude_rad\": %.6f, \"filters\": %.0f}, "
+                    "\"nonfinite_filters\": %lld}\n",
+                    wall * 1e3, std::sqrt(rm[0] / rm[2]), std::sqrt(rm[1] / rm[2]), rm[2], (long long)bad);
+        return bad == 0 ? 0 : 3;
+    }
     std::printf("%s\n", qle_version());
     std::printf("params: update_freq %.1f Hz, measurement_freq %.1f Hz (every %d ticks), num_states %d, direct_orien_method %d, limit %d, corner gate %d, n_tags %d, multirate %d (step delay %d)\n",
                 p.update_freq, p.measurement_freq, d.upd_per_meas, d.num_states, p.direct_orien_method, p.limit_measurement_freq, p.corner_margin_enbl, p.n_tags,

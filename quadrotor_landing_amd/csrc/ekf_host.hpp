@@ -217,8 +217,9 @@ static inline void* mr_ck_slot_host(const qle_batch* h, int64_t t)
     return (char*)h->mr_ckpt + slot_bytes(h) * (size_t)((t / h->mr_k) % h->mr_Nc);
 }
 // the checkpoint copy a predict launch of tick t makes, if any: the grid slot, or the extra slot when t is the tick it was scheduled for
-static inline void* mr_ck_for_predict(qle_batch* h, int64_t t)
+static inline void* mr_ck_for_predict(qle_batch* h, int64_t t, bool* extra)
 {
+    *extra = false;
     if (void* grid = mr_ck_slot_host(h, t)) {
         if (t == h->e_want) h->e_want = -1;          // the grid checkpoint of this tick serves
         return grid;
@@ -226,6 +227,7 @@ static inline void* mr_ck_for_predict(qle_batch* h, int64_t t)
     if (t >= 0 && t == h->e_want) {
         h->e_want = -1;
         h->e_tick = t;
+        *extra = true;
         return (char*)h->mr_ckpt + slot_bytes(h) * (size_t)h->mr_Nc;
     }
     return nullptr;

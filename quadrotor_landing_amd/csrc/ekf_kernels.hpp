@@ -281,7 +281,7 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 template <typename T, bool PFP, int NT, bool MR>
 __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src, T* dst, const T* __restrict__ us,
                                              const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
-                                             T* __restrict__ hist_ck, int64_t i)
+                                             T* __restrict__ hist_ck, bool ck_cached, int64_t i)
 {
     T x[kXW], P[kPW], u[kUW], accel[3];
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
@@ -307,12 +307,23 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
         else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(dst, i, Pn);
         else if (level == 2) store_P_quads_desc<T, q_v, q_th, NT>(dst, i, Pn);
         else store_P_quads_desc<T, 0, q_v, NT>(dst, i, Pn);
-        if (MR && hist_ck) {   // checkpoint copy of the same words, streamed
-            if (level == -1) store_rec<T, kSW, 0, kXW, 2>(hist_ck, i, x);
-            else if (level == 0) store_P_quads_desc<T, q_ab, NQ, 2>(hist_ck, i, Pn);
-            else if (level == 1) store_P_quads_desc<T, q_th, q_ab, 2>(hist_ck, i, Pn);
-            else if (level == 2) store_P_quads_desc<T, q_v, q_th, 2>(hist_ck, i, Pn);
-            else store_P_quads_desc<T, 0, q_v, 2>(hist_ck, i, Pn);
+        if (MR && hist_ck) {
+            // checkpoint copy of the same words: a grid checkpoint is streamed past the caches (it is rarely read again); the extra
+            // checkpoint at the expected entry of the next tag pose is read back a dozen ticks later and is written CACHED, so that it
+            // waits in the Infinity Cache next to the state (wave-uniform choice)
+            if (ck_cached) {
+                if (level == -1) store_rec<T, kSW, 0, kXW, 0>(hist_ck, i, x);
+                else if (level == 0) store_P_quads_desc<T, q_ab, NQ, 0>(hist_ck, i, Pn);
+                else if (level == 1) store_P_quads_desc<T, q_th, q_ab, 0>(hist_ck, i, Pn);
+                else if (level == 2) store_P_quads_desc<T, q_v, q_th, 0>(hist_ck, i, Pn);
+                else store_P_quads_desc<T, 0, q_v, 0>(hist_ck, i, Pn);
+            } else {
+                if (level == -1) store_rec<T, kSW, 0, kXW, 2>(hist_ck, i, x);
+                else if (level == 0) store_P_quads_desc<T, q_ab, NQ, 2>(hist_ck, i, Pn);
+                else if (level == 1) store_P_quads_desc<T, q_th, q_ab, 2>(hist_ck, i, Pn);
+                else if (level == 2) store_P_quads_desc<T, q_v, q_th, 2>(hist_ck, i, Pn);
+                else store_P_quads_desc<T, 0, q_v, 2>(hist_ck, i, Pn);
+            }
         }
     });
 #else
@@ -352,15 +363,15 @@ __device__ __forceinline__ bool cached_workgroup(int32_t split)
 template <typename T, bool PFP, int NT, bool MR>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
-                                                       T* __restrict__ hist_ck, int64_t B, int32_t split)
+                                                       T* __restrict__ hist_ck, int64_t B, int32_t split, int32_t ck_cached)
 {
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {
-        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, i);
-        else predict_tick<T, PFP, 2, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, i);
+        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        else predict_tick<T, PFP, 2, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
     } else {
-        predict_tick<T, PFP, NT, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, i);
+        predict_tick<T, PFP, NT, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
     }
 }
 

@@ -17,11 +17,14 @@ int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, b
     const T* pfp = (const T*)h->pfp;
     // multirate history of this tick: the IMU sample's ring slot and, on checkpoint ticks, the checkpoint slot
     T* hu = history ? (T*)mr_u_slot_host(h, h->tick) : (T*)nullptr;
-    T* hc = history ? (T*)mr_ck_for_predict(h, h->tick) : (T*)nullptr;
+    bool extra_ck = false;
+    T* hc = history ? (T*)mr_ck_for_predict(h, h->tick, &extra_ck) : (T*)nullptr;
+    // the extra checkpoint stays in the Infinity Cache when it fits there next to the state (cached stores), else it is streamed
+    const int32_t ck_cached = extra_ck && 2 * slot_bytes(h) <= ((size_t)200 << 20) ? 1 : 0;
     // QLE_LDS_PAD=bytes (experiments): dynamic LDS the kernel never touches, to cap the workgroups a CU holds (occupancy experiments
     // on the 131 072 ... 524 288-filter plateau, profiles/r03_tuning.md)
     static const size_t lds_pad = [] { const char* s = std::getenv("QLE_LDS_PAD"); return s ? (size_t)std::atoll(s) : (size_t)0; }();
-#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, lds_pad, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, h->B, h->split)
+#define QLE_PRED(F, N, M) hipLaunchKernelGGL((k_predict<T, F, N, M>), g, b, lds_pad, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, h->B, h->split, ck_cached)
 #define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
     const int nt = effective_nt(h);
 #define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)

@@ -83,3 +83,28 @@ def test_driver_in_process_sharding_matches_single_device():
     assert outs[0][0] == outs[1][0] == 3000
     assert abs(outs[0][1] - outs[1][1]) < 1e-4 and abs(outs[0][2] - outs[1][2]) < 1e-4   # printed to 4 decimals
     assert outs[0][3] == outs[1][3]
+
+
+@pytest.mark.gpu
+def test_driver_json_line_for_in_process_sharding():
+    """ekf_driver --devices N --json: the in-process sharding (one handle + stream + host thread per device, no torchrun) prints ONE
+    JSON line with the fields of bench.py's line; the shards cover the population exactly, start their timed ticks together, and
+    `value` is the whole population over the slowest shard's device time."""
+    import json
+    exe = os.path.join(ROOT, "quadrotor_landing_amd", "ekf_driver")
+    subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc")], check=True, capture_output=True)
+    cmd = [exe, "--config", os.path.join(ROOT, "quadrotor_landing_amd", "config", "ekf_sim_rotors.yaml"), "--batch", "5000", "--ticks", "280",
+           "--dtype", "f32", "--devices", "3", "--corner-gate", "0", "--json"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "higher_is_better", "scaling", "dtype", "data", "config", "per_shard"):
+        assert k in d, k
+    assert d["n_gpus"] == 3 and d["steps"] == 280 and d["scaling"] == "strong" and d["config"]["global_batch"] == 5000
+    sh = d["per_shard"]
+    assert [s_["filters"] for s_ in sh] == [1667, 1667, 1666] and [s_["filter_offset"] for s_ in sh] == [0, 1667, 3334]
+    assert abs(d["ms_per_step"] * 280 - max(s_["hip_event_ms"] for s_ in sh)) < 1e-3
+    assert abs(d["value"] - 5000 * 280 / (d["ms_per_step"] * 280 * 1e-3)) / d["value"] < 1e-4
+    assert d["nonfinite_filters"] == 0 and d["rmse_vs_truth"]["filters"] == 5000 and d["rmse_vs_truth"]["position_m"] < 0.5
