@@ -27,6 +27,12 @@
 
 namespace qle {
 
+// Cache policy of the stores into the IMU ring of the multirate history (0 cached, 2 non-temporal).  Measured on cfg3mr
+// (profiles/r03_tuning.md): cached ring stores make the correcting tick's sample loads cheaper and every predict tick dearer
+// (10.1 -> 10.7 us); the whole schedule moves by +0.6 %, inside the box-to-box spread: the ring stays streamed.
+#ifndef QLE_RING_POLICY
+#define QLE_RING_POLICY 2
+#endif
 constexpr int kBlock = 256;
 constexpr int kTile = 64;   // filters per tile = wavefront size
 
@@ -343,7 +349,7 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     if (dead) return;
     if (MR) {
         const T uk[kHW] = {u[0], u[1], u[2], u[3], u[4], u[5], T(0), T(0)};
-        store_rec<T, kHW, 0, kHW, 2>(hist_u, i, uk);
+        store_rec<T, kHW, 0, kHW, QLE_RING_POLICY>(hist_u, i, uk);
     }
     if (aux_accel) {  // optional side output (wave-uniform), AoS [B][3] in the compute dtype
 #pragma unroll
@@ -718,7 +724,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
                         store_rec<T, kSW, 0, kXW>(cur, i, x);
                         store_rec<T, kSW, kXW, kPW>(cur, i, P);
                         const T uk[kHW] = {u6[0], u6[1], u6[2], u6[3], u6[4], u6[5], T(0), T(0)};
-                        store_rec<T, kHW, 0, kHW, 2>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
+                        store_rec<T, kHW, 0, kHW, QLE_RING_POLICY>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
                     }
                     if (ck) {
                         T* ckp = extra ? ckpt + (int64_t)m.Nc * m.slot_words : mr_ck_slot(ckpt, m, t);
