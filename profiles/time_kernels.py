@@ -2,7 +2,9 @@
 """Per-kernel launch time of the hot kernels (HIP events, back-to-back launches): a tick whose tag record corrects every
 filter, one whose mask is all zero, and a predict-only tick.
 
-    [QLE_QUAD=0|1|2|3|7] [QLE_LIB=...] python profiles/time_kernels.py <batch> <f32|f64> [label]
+    [QLE_QUAD=0|1|2|3|7] [QLE_LIB=...] [QLE_TIME_DIRECT=0] python profiles/time_kernels.py <batch> <f32|f64> [label]
+
+QLE_TIME_DIRECT=0 times the conventional orientation method (direct_orien_method = 0, the reference's default, EKF.cpp:440-444).
 """
 import json
 import os
@@ -14,10 +16,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import quadrotor_landing_amd as qla  # noqa: E402
 from bench import CFG3  # noqa: E402
 
+CFG3 = dict(CFG3, direct_orien_method=int(os.environ.get("QLE_TIME_DIRECT", "1")))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 dtype = sys.argv[2] if len(sys.argv) > 2 else "f32"
 N = int(os.environ.get("QLE_TIME_N", "300"))
-out = {"label": sys.argv[3] if len(sys.argv) > 3 else "", "batch": B, "dtype": dtype, "quad": os.environ.get("QLE_QUAD", "auto"),
+out = {"label": sys.argv[3] if len(sys.argv) > 3 else "", "batch": B, "dtype": dtype, "direct": CFG3["direct_orien_method"], "quad": os.environ.get("QLE_QUAD", "auto"),
        "lib": os.path.basename(os.environ.get("QLE_LIB", "default"))}
 for name, mask_all in (("step_all_us", True), ("step_none_us", False)):
     ekf = qla.BatchedRelativePoseEKF(B, dtype, **CFG3)
