@@ -79,7 +79,9 @@ def main():
         lines += ["## per-kernel launch resources (first dispatch)", "", "| kernel | VGPR | AGPR | SGPR | scratch B | LDS B | workgroup | grid |", "|---|---|---|---|---|---|---|---|"]
         for k, r in seen.items():
             lines.append(f"| `{k}` | {r.get('VGPR_Count')} | {r.get('Accum_VGPR_Count')} | {r.get('SGPR_Count')} | {r.get('Scratch_Size')} | {r.get('LDS_Block_Size')} | {r.get('Workgroup_Size_X')} | {r.get('Grid_Size_X')} |")
-        lines.append("")
+        lines += ["", "(rocprofv3's `VGPR_Count` on gfx950 reads about HALF the registers the compiler allocates per lane -- e.g. 92 for the 179-register "
+                  "`k_predict<float>` -- and `Accum_VGPR_Count` likewise; the allocation figures quoted in DESIGN.md come from "
+                  "`quadrotor_landing_amd/csrc/resources.py`, i.e. hipcc's `-Rpass-analysis=kernel-resource-usage`.)", ""]
     agg = counter_means(src)
     if agg:
         lines += ["## PMC counters", "", "| kernel | counter | dispatches | mean value per dispatch |", "|---|---|---|---|"]
