@@ -228,6 +228,10 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
             }
         }
         mine[kLdsFlag] = T((live ? 1 : 0) | (corr ? 2 : 0));
+        // "does any filter of this workgroup correct": decided here, once, by the wave that knows (read by everyone after the first
+        // barrier; a vote at the second barrier instead -- __syncthreads_or -- is two barriers)
+        const bool any_corr = __ballot(corr) != 0;   // evaluated by every lane of the scalar role, written by one
+        if (STEP && l == 0) lds[FPW * kLdsStride] = T(any_corr ? 1 : 0);
     } else if (helper_wave) {
         // waves 1 and 2, filter t % 64: what the correction needs of the predicted NOMINAL state only, side by side with wave 0.
         // INVARIANT (no barrier orders these waves' load of x against wave 0's in-place store of the predicted x): wave 0 stores x
@@ -302,7 +306,8 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
             rec[kLdsU2 + 18 + 3 * i + j] = Ptt[i];
         }
     }
-    if (!__syncthreads_or(corr_q ? 1 : 0)) return;   // nobody in this tile corrects
+    if (lds[FPW * kLdsStride] == T(0)) return;   // nobody in this workgroup corrects (wave-uniform, written before the first barrier)
+    __syncthreads();
 
     // ---- scalar role: innovation, S = G P G^T + R_k = L D L^T
     const bool corr_s = scalar_wave && ((int)mine[kLdsFlag] & 2) != 0;
@@ -369,7 +374,7 @@ __global__ __launch_bounds__(kBlock, WgWaves<T>::value) void kw_tick(DevParams<T
                                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
                                                                       int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
 {
-    __shared__ T lds[FPW * kLdsStride];
+    __shared__ T lds[FPW * kLdsStride + 2];   // the per-filter records + the workgroup's "somebody corrects" word
     constexpr int PER = kTile / FPW;
     const int64_t wg = batch_block();
     const int64_t tile = wg / PER;
