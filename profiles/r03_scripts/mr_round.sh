@@ -15,3 +15,4 @@ import json; d=json.load(open('$O/bench_mr.json')); print('cfg3mr ticks/s %.3e  
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_mr -o s -- python3 bench.py --workload cfg3mr --no-cpu-baseline --no-extras --steps 1400 > $O/stats_mr.log 2>&1
 python3 profiles/summarize.py $O/stats_mr $O/kernel_stats_multirate.md "bench.py --workload cfg3mr --steps 1400"
 sed -n 7,12p $O/kernel_stats_multirate.md | cut -c1-160
+python3 profiles/r03_scripts/after_step.py $O/stats_mr k_step_mr > $O/after_step.md; cat $O/after_step.md
