@@ -276,6 +276,9 @@ typedef struct qle_policy {
     int32_t ring_slots;     /* state ring capacity (1 = single-rate, in place) */
     int64_t state_bytes;    /* bytes of one state slot (144 words x padded batch) */
     int64_t ring_bytes;     /* state_bytes x ring_slots */
+    int32_t record_words;   /* state words a tick reads and writes per filter: 136 (x 16 + packed P 120), or 64 with compact records
+                               (est_bias = false, relative_pose_EKF.cpp:92: x 16 + the 45 words of the 9 x 9 pose block + 3 pad) */
+    int32_t reserved;
 } qle_policy;
 int qle_get_policy(const qle_batch *h, qle_policy *out);
 /* Algorithmic HBM bytes one launch moves:

@@ -58,7 +58,7 @@ class QleSynthCfg(C.Structure):
 class QlePolicy(C.Structure):
     """`struct qle_policy`: how a handle launches its ticks."""
     _fields_ = [("state_policy", _i32), ("refresh_period", _i32), ("split_k64", _i32), ("block", _i32), ("coop_ticks", _i32),
-                ("ring_slots", _i32), ("state_bytes", _i64), ("ring_bytes", _i64)]
+                ("ring_slots", _i32), ("state_bytes", _i64), ("ring_bytes", _i64), ("record_words", _i32), ("reserved", _i32)]
 
 
 class QleError(RuntimeError):

@@ -114,6 +114,7 @@ static int check_handle(const qle_batch* h)
     return QLE_OK;
 }
 
+static void choose_cache_policy(qle_batch* h);
 extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
 {
     QLE_TRY(check_handle(h));
@@ -168,10 +169,22 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
         h->hist_first = hf; h->stamp = stp; h->delay_cur = dc; h->mr_u = mu; h->mr_ckpt = mc; h->mr_anchor = ma;
         h->mr_Nc = Nc; h->mr_Cu = Cu;
     }
+    // Record layout (ekf_kernels.hpp): est_bias = false without the multirate history keeps only the 9 x 9 pose block of P (compact
+    // records, 64 words moved per direction instead of 136) on the batch sizes the lane-per-filter kernels serve; the workgroup-cooperative
+    // kernels of the small batches (latency-bound, not byte-bound) and the multirate history work on full records.  QLE_COMPACT=0|1 forces it.
+    bool compact = !p->est_bias && !mr && h->quad == 0;
+    if (const char* s = std::getenv("QLE_COMPACT")) compact = std::atoi(s) != 0 && !p->est_bias && !mr;
+    if (compact != h->compact && h->state_set) {   // a live state changes layout with the parameters
+        if (h->dtype == QLE_F32) hipLaunchKernelGGL((k_relayout_P<float>), grid_for(h, 256), dim3(256), 0, h->stream, (float*)h->ring, (int)h->compact, (int)compact, h->B);
+        else hipLaunchKernelGGL((k_relayout_P<double>), grid_for(h, 256), dim3(256), 0, h->stream, (double*)h->ring, (int)h->compact, (int)compact, h->B);
+        HIP_TRY(hipGetLastError());
+    }
+    if (compact != h->compact) { h->compact = compact; choose_cache_policy(h); }
     h->pub = *p;
     h->der = d;
     h->pf = make_dev<float>(*p, d);
     h->pd = make_dev<double>(*p, d);
+    h->pf.compact = h->pd.compact = compact ? 1 : 0;
     h->mr = mr;
     if (mr) h->uniform_age = p->measurement_delay;
     h->hist_dirty = true;  // the multirate history restarts from the current state
@@ -194,6 +207,32 @@ extern "C" int qle_destroy(qle_batch* h)
     return QLE_OK;
 }
 
+static void choose_cache_policy(qle_batch* h)
+{   // Cache policy of the state accesses, from SUSTAINED rates on MI355X (profiles/r01_tuning.md section 5;
+        // the input records are always read non-temporally):
+        //   state <= 40 MiB (about the aggregate L2): non-temporal loads and stores with a cached-store tick every
+        //     128 ticks that keeps the state allocated in the Infinity Cache (effective_nt below);
+        //   up to 48 MiB: non-temporal loads, cached stores;
+        //   up to 300 MiB: cached loads and stores (Infinity-Cache resident from tick to tick);
+        //   beyond: "split" -- a fixed ~216 MiB of the state stays cached, the rest streams non-temporally, so the
+        //     Infinity Cache and HBM serve the tick side by side (+25 % at 432 and 576 MiB, +17 % at 1.1 GB, +8 % at
+        //     2.3 GB over streaming everything).
+        // QLE_NT=0|1|2|3 overrides (0 cached, 1 the L2-sized scheme, 2 non-temporal loads+stores, 3 split with
+        // QLE_SPLIT=-k: k of every 64 workgroup groups cached).
+        // (compact records: only 64 of a record's 144 words are ever touched, qle_set_params)
+        const double state_mib = (double)(h->compact ? kXW + kPWc : kSW) * (double)h->Bp * (double)h->wsz / (1024.0 * 1024.0);
+        h->nt = state_mib <= 48.0 ? 1 : (state_mib <= 300.0 ? 0 : 3);
+        h->nt_refresh = state_mib <= 40.0 ? 128 : 0;   // at 45 MiB the refresh scheme loses (18.2 vs 16.3 us), plain policy 1 wins
+        if (const char* s = std::getenv("QLE_REFRESH")) h->nt_refresh = std::max(0, std::atoi(s));
+        // larger than the cache: keep about 216 MiB of the state cached (k of every 64 workgroup groups, interleaved
+        // over the batch and spread evenly over the XCDs) and stream the rest
+        const int k64 = (int)std::lround(64.0 * 216.0 / std::max(state_mib, 1.0));
+        h->split = -std::min(63, std::max(1, k64));
+        if (state_mib > 64.0 * 240.0) h->nt = 2;       // even 1/64 of it would not fit: stream everything
+        if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(3, std::max(0, std::atoi(s)));
+        if (const char* s = std::getenv("QLE_SPLIT")) h->split = std::atoi(s);
+    }
+
 extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t device, const qle_params* p)
 {
     if (!out) return fail(QLE_ERR_INVALID, "out is null");
@@ -214,29 +253,7 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     h->dtype = dtype;
     h->device = device;
     h->wsz = dtype == QLE_F32 ? 4 : 8;
-    {   // Cache policy of the state accesses, from SUSTAINED rates on MI355X (profiles/r01_tuning.md section 5;
-        // the input records are always read non-temporally):
-        //   state <= 40 MiB (about the aggregate L2): non-temporal loads and stores with a cached-store tick every
-        //     128 ticks that keeps the state allocated in the Infinity Cache (effective_nt below);
-        //   up to 48 MiB: non-temporal loads, cached stores;
-        //   up to 300 MiB: cached loads and stores (Infinity-Cache resident from tick to tick);
-        //   beyond: "split" -- a fixed ~216 MiB of the state stays cached, the rest streams non-temporally, so the
-        //     Infinity Cache and HBM serve the tick side by side (+25 % at 432 and 576 MiB, +17 % at 1.1 GB, +8 % at
-        //     2.3 GB over streaming everything).
-        // QLE_NT=0|1|2|3 overrides (0 cached, 1 the L2-sized scheme, 2 non-temporal loads+stores, 3 split with
-        // QLE_SPLIT=-k: k of every 64 workgroup groups cached).
-        const double state_mib = (double)kSW * (double)h->Bp * (double)h->wsz / (1024.0 * 1024.0);
-        h->nt = state_mib <= 48.0 ? 1 : (state_mib <= 300.0 ? 0 : 3);
-        h->nt_refresh = state_mib <= 40.0 ? 128 : 0;   // at 45 MiB the refresh scheme loses (18.2 vs 16.3 us), plain policy 1 wins
-        if (const char* s = std::getenv("QLE_REFRESH")) h->nt_refresh = std::max(0, std::atoi(s));
-        // larger than the cache: keep about 216 MiB of the state cached (k of every 64 workgroup groups, interleaved
-        // over the batch and spread evenly over the XCDs) and stream the rest
-        const int k64 = (int)std::lround(64.0 * 216.0 / std::max(state_mib, 1.0));
-        h->split = -std::min(63, std::max(1, k64));
-        if (state_mib > 64.0 * 240.0) h->nt = 2;       // even 1/64 of it would not fit: stream everything
-        if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(3, std::max(0, std::atoi(s)));
-        if (const char* s = std::getenv("QLE_SPLIT")) h->split = std::atoi(s);
-    }
+    choose_cache_policy(h);
     // Workgroup-cooperative tick kernel (ekf_quad_kernels.hpp: scalar waves + covariance quads, 45 covariance values per lane).
     // Measured (profiles/r02_tuning.md section 2): it wins on ticks that carry corrections while the chip is not full -- up to 16 384
     // filters in both dtypes (fp64 4 096 filters, BASELINE cfg 2: 12.9 vs 18.9 us per tick; fp32: 8.2 vs 9.5 us) -- and loses beyond
@@ -290,7 +307,8 @@ extern "C" int32_t qle_num_states(const qle_batch* h) { return h ? h->der.num_st
 extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
 {   // packed P, SoA, one streamed tick
     if (!h) return 0;
-    int64_t words = kind == 0 ? (16 + 120 + 6) + 136 : kind == 1 ? (16 + 120 + 6 + 7) + 136 : (16 + 120 + 7) + 136;
+    const int64_t rec = h->compact ? 16 + kPWc : 136;   // state words a tick reads and writes (compact records: x + the 9 x 9 pose block of P)
+    int64_t words = kind == 0 ? (rec + 6) + rec : kind == 1 ? (rec + 6 + 7) + rec : (rec + 7) + rec;
     if (h->pfp_on) words += kFW;
     int64_t bytes = words * (int64_t)h->wsz * h->B;
     // a multirate predict tick also appends to the history: the IMU sample (6 words + 2 pad) and, every mr_k-th tick, a checkpoint
@@ -307,6 +325,8 @@ extern "C" int qle_get_policy(const qle_batch* h, qle_policy* out)
     out->block = h->block;
     out->coop_ticks = h->mr ? 0 : h->quad;
     out->ring_slots = h->mr ? h->mr_Nc + 1 : 1;
+    out->record_words = h->compact ? kXW + kPWc : kXW + kPW;
+    out->reserved = 0;
     out->state_bytes = (int64_t)slot_bytes(h);
     // what a tick touches again later: the state itself, plus (multirate) the history it streams to
     out->ring_bytes = (int64_t)slot_bytes(h) * (h->mr ? (3 + h->mr_Nc) : 1) + (h->mr ? (int64_t)h->mr_Cu * kHW * h->Bp * (int64_t)h->wsz : 0);
@@ -388,7 +408,7 @@ static int pack_P(qle_batch* h, const double* P, void* dst)
         const int64_t m = std::min(kStageFilters, h->B - i0);
         HIP_TRY(hipMemcpyAsync(h->stage, P + i0 * n * n, (size_t)m * n * n * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL((k_pack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const double*)h->stage, n, (T*)dst,
-                           i0, m);
+                           i0, m, (int)h->compact);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(h->stream));
     }
@@ -400,7 +420,7 @@ static int unpack_P(qle_batch* h, const void* src, double* P)
     const int n = h->der.num_states;
     for (int64_t i0 = 0; i0 < h->B; i0 += kStageFilters) {
         const int64_t m = std::min(kStageFilters, h->B - i0);
-        hipLaunchKernelGGL((k_unpack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, n, h->stage, i0, m);
+        hipLaunchKernelGGL((k_unpack_P_off<T>), dim3((unsigned)((m + 255) / 256)), dim3(256), 0, h->stream, (const T*)src, n, h->stage, i0, m, (int)h->compact);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(P + i0 * n * n, h->stage, (size_t)m * n * n * sizeof(double), hipMemcpyDeviceToHost, h->stream));
         HIP_TRY(hipStreamSynchronize(h->stream));
@@ -565,7 +585,7 @@ extern "C" int qle_predict(qle_batch* h, const double* u)
     if (!u) return fail(QLE_ERR_INVALID, "u is null");
     QLE_TRY(BY_DTYPE(h, pack_rows, h, u, kUW, kUW, h->tick_u, kUW, 0));
     h->hist_dirty = true;  // a bare prediction_step is not a filter tick: the multirate history restarts
-    if (h->quad & 2) return BY_DTYPE(h, launch_quad, h, h->tick_u, nullptr);
+    if ((h->quad & 2) && !h->compact) return BY_DTYPE(h, launch_quad, h, h->tick_u, nullptr);
     return BY_DTYPE(h, launch_predict_sd, h, h->tick_u, state_cur(h), state_cur(h), false);
 }
 extern "C" int qle_update(qle_batch* h, const double* z, const uint8_t* mask)

@@ -133,6 +133,7 @@ struct DevParams {
     T R[6];          // diag(R_r,R_ang) (EKF.cpp:116-118)
     T ab_static[3];  // EKF.cpp:357
     T wb_static[3];  // EKF.cpp:358
+    int32_t compact; // state records hold the 9 x 9 pose block of P only (est_bias = false, EKF.cpp:92; ekf_kernels.hpp)
 };
 
 // Noise / static-bias values a tick actually uses: shared or per filter (cfg 5).

@@ -57,7 +57,7 @@ __host__ __device__ constexpr int block_row_last_word(int b)
 
 // x: state at tick n-1 in, state at tick n out.  Po: covariance at tick n-1.  `corr`: this lane fuses the tag pose z; `live`: the
 // filter is initialised (a lane that is not stores nothing: corr implies live).
-// emit_accel(accel) / emit_obs(obs): side outputs as soon as they exist.  store_quad(q4, ptr to 4 final words): 4-word group q4 of
+// emit_accel(accel) / emit_obs(obs): side outputs as soon as they exist.  store_quad(q4 as a std::integral_constant, ptr to 4 final words): 4-word group q4 of
 // the new covariance is final (called for q4 = 29 .. 0 on every lane); store_x(): x is final.
 template <typename T, bool DIRECT, typename EmitAccel, typename EmitObs, typename StoreX, typename StoreQuad>
 __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Noise<T>& nzl, T (&x)[16], const T (&Po)[120], const T (&u)[6],
@@ -126,7 +126,7 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
 #pragma unroll
             for (int m = 0; m < 6; ++m) acc += NV[i][m] * V[k][m];
             Pn[w] = acc;
-            if constexpr (w % 4 == 0) store_quad(w / 4, &Pn[w]);
+            if constexpr (w % 4 == 0) store_quad(std::integral_constant<int, w / 4>{}, &Pn[w]);
         });
         // Nothing the downdate needs depends on the innovation: dy, its elimination yd = D^-1 L^-1 dy, dx and the injection come AFTER the
         // sweep, where they run under the drain of the covariance stores.  The tag pose is made to depend on the last covariance word so
@@ -164,7 +164,7 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
         store_x();
         static_for<0, kPW_ / 4>([&](auto qc) {
             constexpr int q4 = kPW_ / 4 - 1 - decltype(qc)::value;
-            store_quad(q4, &Pn[4 * q4]);
+            store_quad(std::integral_constant<int, q4>{}, &Pn[4 * q4]);
         });
     }
 }

@@ -76,6 +76,7 @@ struct qle_batch {
     uint8_t* stage_mask = nullptr;
     unsigned long long* counter = nullptr;
     bool state_set = false;
+    bool compact = false;       // records hold the 9 x 9 pose block of P only (est_bias = false; qle_set_params, ekf_kernels.hpp)
     // device-side measurement gating (EKF.cpp:147-186)
     bool gating = false;
     int32_t* last_corr = nullptr;  // [B] index of each filter's last correcting tick, -1 = never
@@ -133,6 +134,7 @@ template <typename T> static DevParams<T> make_dev(const qle_params& p, const ql
     for (int i = 0; i < 9; ++i) o.C_vc[i] = (T)d.C_vc[i];
     for (int i = 0; i < 12; ++i) o.Q[i] = (T)d.Q[i];
     for (int i = 0; i < 6; ++i) o.R[i] = (T)d.R[i];
+    o.compact = 0;   // set by qle_set_params
     return o;
 }
 template <typename T> static const DevParams<T>& dev(const qle_batch* h);
@@ -160,7 +162,7 @@ static inline int effective_nt(const qle_batch* h)
 }
 
 // Workgroup-cooperative tick kernel (ekf_quad_kernels.hpp): the single-rate tick in place, one 256-thread workgroup per tile.
-static inline bool use_quad(const qle_batch* h, int bit) { return (h->quad & bit) != 0 && !h->mr; }
+static inline bool use_quad(const qle_batch* h, int bit) { return (h->quad & bit) != 0 && !h->mr && !h->compact; }
 
 static inline GateParams make_gate(const qle_batch* h)
 {
@@ -256,3 +258,8 @@ template <typename T> int run_resident_t(qle_batch* h, const qle_inputs* in, int
 template <typename T> int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool history);   // tu_predict: k_predict
 template <typename T> int launch_step_lane(qle_batch* h, const void* u, const void* z);        // tu_step: k_step
 template <typename T> int launch_quad(qle_batch* h, const void* u, const void* z);             // tu_quad: kw_tick
+// tu_compact: the same lane-per-filter kernels instantiated for compact records (h->compact)
+template <typename T> int launch_predict_compact(qle_batch* h, const void* u, const void* src, void* dst);
+template <typename T> int launch_step_compact(qle_batch* h, const void* u, const void* z);
+template <typename T> int launch_update_compact(qle_batch* h, const void* z);
+template <typename T> int run_resident_compact(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n);

@@ -168,6 +168,53 @@ __device__ __forceinline__ void store_rec(T* __restrict__ base, int64_t i, const
     for (int k = 0; k < NF; ++k) st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + ((W0 / VW + k) * kTile + lane) * VW), pack_quad(&r[k * VW]));
 }
 
+// Compact records: est_bias = false (EKF.cpp:92, num_states = 9) without the multirate history.  The bias blocks of such a filter's P are
+// identically zero (no process noise, no coupling: EKF.cpp:405-409), so its record keeps only the 45 words of the 9 x 9 pose block, as
+// their own row-major triangle in record words 16..60 (3 words of padding): a tick moves 16 + 48 words per direction instead of 136.
+// The arithmetic runs on the same 15-state register image (zeros in the bias blocks), which is what the full-record path computes too.
+constexpr int kPWc = 48;
+__host__ __device__ constexpr int sidx9(int i, int j) { return i * 9 - i * (i - 1) / 2 + (j - i); }   // i <= j < 9
+// record word of P(a, b), a <= b, or -1 when a compact record does not hold it
+__host__ __device__ constexpr int p_word(int a, int b, bool compact)
+{
+    return compact ? (b < 9 ? kXW + sidx9(a, b) : -1) : kXW + sidx(a, b);
+}
+template <typename T, int NT = 0>
+__device__ __forceinline__ void load_P_compact(const T* __restrict__ st, int64_t i, T (&P)[kPW])
+{
+    T t[kPWc];
+    load_rec<T, kSW, kXW, kPWc, NT>(st, i, t);
+#pragma unroll
+    for (int a = 0; a < 15; ++a)
+#pragma unroll
+        for (int b = a; b < 15; ++b) P[sidx(a, b)] = b < 9 ? t[sidx9(a, b)] : T(0);
+}
+template <typename T, int NT = 0>
+__device__ __forceinline__ void store_P_compact(T* __restrict__ st, int64_t i, const T (&P)[kPW])
+{
+    T t[kPWc];
+#pragma unroll
+    for (int k = 45; k < kPWc; ++k) t[k] = T(0);
+#pragma unroll
+    for (int a = 0; a < 9; ++a)
+#pragma unroll
+        for (int b = a; b < 9; ++b) t[sidx9(a, b)] = P[sidx(a, b)];
+    store_rec<T, kSW, kXW, kPWc, NT>(st, i, t);
+}
+// the P part of a state record, either layout (wave-uniform choice)
+template <typename T, int NT = 0>
+__device__ __forceinline__ void load_P_any(const T* __restrict__ st, int64_t i, T (&P)[kPW], bool compact)
+{
+    if (compact) load_P_compact<T, NT>(st, i, P);
+    else load_rec<T, kSW, kXW, kPW, NT>(st, i, P);
+}
+template <typename T, int NT = 0>
+__device__ __forceinline__ void store_P_any(T* __restrict__ st, int64_t i, const T (&P)[kPW], bool compact)
+{
+    if (compact) store_P_compact<T, NT>(st, i, P);
+    else store_rec<T, kSW, kXW, kPW, NT>(st, i, P);
+}
+
 template <typename T, bool PFP>
 __device__ __forceinline__ void load_noise(const DevParams<T>& p, const T* __restrict__ pfp, int64_t i, Noise<T>& nz)
 {
@@ -284,7 +331,7 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 // before its first store).  MR (multirate filter): the tick also appends to the history -- the IMU sample goes to its slot
 // of the IMU ring (hist_u, EKF.cpp:254-256) and on checkpoint ticks the new state is copied to its checkpoint slot
 // (hist_ck != nullptr, wave-uniform); see k_step_mr for the history scheme.
-template <typename T, bool PFP, int NT, bool MR>
+template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false>
 __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src, T* dst, const T* __restrict__ us,
                                              const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
                                              T* __restrict__ hist_ck, bool ck_cached, int64_t i)
@@ -297,7 +344,8 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
 #if QLE_PREDICT_LEVELS
     constexpr int VW = Quad<T>::VW;
     constexpr int NQ = kPW / VW;
-    load_P_quads_desc<T, 0, NQ, NT>(src, i, P);
+    if constexpr (COMPACT) load_P_compact<T, NT>(src, i, P);
+    else load_P_quads_desc<T, 0, NQ, NT>(src, i, P);
     // A filter that is not initialised is left untouched.  No early exit: the compiler would sink the covariance loads below such a
     // branch and every wave would wait for x before it even issues them (+1 us per tick at 65 536 filters, profiles/r02_tuning.md).
     // Instead the lane computes on (with a unit quaternion, so that its arithmetic stays finite) and only its stores are masked.
@@ -309,6 +357,7 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     ekf_predict_levels<T>(p, nz, x, P, u, accel, Pn, [&](int level) {
         if (dead) return;
         if (level == -1) store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
+        else if (COMPACT) { if (level == 3) store_P_compact<T, NT>(dst, i, Pn); }
         else if (level == 0) store_P_quads_desc<T, q_ab, NQ, NT>(dst, i, Pn);
         else if (level == 1) store_P_quads_desc<T, q_th, q_ab, NT>(dst, i, Pn);
         else if (level == 2) store_P_quads_desc<T, q_v, q_th, NT>(dst, i, Pn);
@@ -333,13 +382,13 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
         }
     });
 #else
-    load_rec<T, kSW, kXW, kPW, NT>(src, i, P);
+    load_P_any<T, NT>(src, i, P, COMPACT);
     const bool dead = filter_uninitialised(x);
     if (dead) x[9] = T(1);
     ekf_predict<T>(p, nz, x, P, u, accel);
     if (!dead) {
         store_rec<T, kSW, 0, kXW, NT>(dst, i, x);
-        store_rec<T, kSW, kXW, kPW, NT>(dst, i, P);
+        store_P_any<T, NT>(dst, i, P, COMPACT);
         if (MR && hist_ck) {
             store_rec<T, kSW, 0, kXW, 2>(hist_ck, i, x);
             store_rec<T, kSW, kXW, kPW, 2>(hist_ck, i, P);
@@ -366,7 +415,7 @@ __device__ __forceinline__ bool cached_workgroup(int32_t split)
     return split >= 0 ? blockIdx.x < (unsigned)split : ((blockIdx.x >> 3) & 63u) < (unsigned)(-split);
 }
 
-template <typename T, bool PFP, int NT, bool MR>
+template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
                                                        T* __restrict__ hist_ck, int64_t B, int32_t split, int32_t ck_cached)
@@ -374,17 +423,17 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {
-        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
-        else predict_tick<T, PFP, 2, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        else predict_tick<T, PFP, 2, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
     } else {
-        predict_tick<T, PFP, NT, MR>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        predict_tick<T, PFP, NT, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
     }
 }
 
 // Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290): predict, then correct where the record's mask word is
 // non-zero, as one straight-line schedule (ekf_step_fused, ekf_fused.hpp).
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
-template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
+template <typename T, bool DIRECT, bool PFP, bool GATE, int NT, bool COMPACT = false>
 __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParams& gp, T* st, const T* __restrict__ us,
                                           const T* __restrict__ zs, const T* __restrict__ pfp,
                                           T* __restrict__ aux_accel, T* __restrict__ aux_obs,
@@ -396,7 +445,7 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     load_rec<T, kUW, 0, kUW, NT>(us, i, u);
     load_rec<T, kZW, 0, kZW, NT>(zs, i, zr);
     load_rec<T, kSW, 0, kXW, NT>(st, i, x);
-    load_rec<T, kSW, kXW, kPW, NT>(st, i, Po);   // ascending: the fused schedule starts with rows r
+    load_P_any<T, NT>(st, i, Po, COMPACT);   // ascending: the fused schedule starts with rows r
     const bool dead = filter_uninitialised(x);   // left untouched; no early exit (see predict_tick)
     if (dead) x[9] = T(1);
     bool corr = !dead && zr[7] != T(0);
@@ -416,6 +465,7 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
     T* tb = st + wave_tile(i) * (int64_t)(kSW * kTile);
     const int lane = (int)(i & 63);
+    T Pc[kPWc];   // compact records only: written group by group in the final sweep (every pose-block word is in one), never otherwise
     ekf_step_fused<T, DIRECT>(p, nz, x, Po, u, z, corr, !dead,
         [&](const T (&accel)[3]) {
             if (aux_accel && !dead) {   // optional side outputs (wave-uniform), written as soon as they exist
@@ -430,16 +480,28 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
             }
         },
         [&]() { store_rec<T, kSW, 0, kXW, NT>(st, i, x); },
-        [&](int q4, const T* w4) {   // q4 = index of a 4-word group of P; one 16-byte quad in fp32, two in fp64
+        [&](auto qc, const T* w4) {   // q4 = index of a 4-word group of P; one 16-byte quad in fp32, two in fp64
+            constexpr int q4 = decltype(qc)::value;
+            if constexpr (COMPACT) {   // compact records: the words of the pose block are collected and stored once, below
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (word_col(4 * q4 + k) < 9) Pc[sidx9(word_row(4 * q4 + k), word_col(4 * q4 + k))] = w4[k];
+                return;
+            }
 #pragma unroll
             for (int h = 4 / VW - 1; h >= 0; --h) {
                 const int qr = kXW / VW + q4 * (4 / VW) + h;
                 st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + (qr * kTile + lane) * VW), pack_quad(w4 + h * VW));
             }
         });
+    if (COMPACT && !dead) {
+#pragma unroll
+        for (int k = 45; k < kPWc; ++k) Pc[k] = T(0);
+        store_rec<T, kSW, kXW, kPWc, NT>(st, i, Pc);
+    }
 }
 
-template <typename T, bool DIRECT, bool PFP, bool GATE, int NT>
+template <typename T, bool DIRECT, bool PFP, bool GATE, int NT, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
                                                  const T* __restrict__ zs, const T* __restrict__ pfp,
                                                  T* __restrict__ aux_accel, T* __restrict__ aux_obs,
@@ -448,10 +510,10 @@ __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(DevPara
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {   // see k_predict
-        if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
-        else step_tick<T, DIRECT, PFP, GATE, 2>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0, COMPACT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        else step_tick<T, DIRECT, PFP, GATE, 2, COMPACT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
     } else {
-        step_tick<T, DIRECT, PFP, GATE, NT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
+        step_tick<T, DIRECT, PFP, GATE, NT, COMPACT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
     }
 }
 
@@ -756,7 +818,7 @@ __global__ void k_fill_i32(I* __restrict__ dst, I v, int64_t B)
 // filter (predict every tick, correct where the tick has a tag record whose mask word is set).
 // Per tick only the 6-word IMU record (and the 8-word tag record on measurement ticks) is read;
 // the next tick's IMU record is loaded before the current tick's arithmetic.
-template <typename T, bool DIRECT, bool PFP>
+template <typename T, bool DIRECT, bool PFP, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, const T* __restrict__ us, const T* __restrict__ zs,
                                                          const int32_t* __restrict__ slot, int64_t pitch_u, int64_t pitch_z, int64_t T_seq,
                                                          int64_t t0, int64_t n, const T* __restrict__ pfp, int64_t B)
@@ -765,7 +827,7 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
     if (i >= B) return;
     T x[kXW], P[kPW], u[kUW], un[kUW], accel[3];
     load_rec<T, kSW, 0, kXW>(st, i, x);
-    load_rec<T, kSW, kXW, kPW>(st, i, P);
+    load_P_any<T>(st, i, P, COMPACT);
     if (filter_uninitialised(x)) return;
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
@@ -787,7 +849,7 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
         t = tn;
     }
     store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_rec<T, kSW, kXW, kPW>(st, i, P);
+    store_P_any<T>(st, i, P, COMPACT);
 }
 
 // Shift the tick origin: subtract `shift` from every filter's last-correction index so that the
@@ -816,7 +878,7 @@ __global__ void k_upds_since(const T* __restrict__ st, const int32_t* __restrict
 }
 
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
-template <typename T, bool DIRECT, bool PFP>
+template <typename T, bool DIRECT, bool PFP, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ st, const T* __restrict__ zs,
                                                    const T* __restrict__ pfp, T* __restrict__ aux_obs, int64_t B)
 {
@@ -827,7 +889,7 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
     if (zr[7] == T(0)) return;
     T x[kXW], P[kPW];
     load_rec<T, kSW, 0, kXW>(st, i, x);
-    load_rec<T, kSW, kXW, kPW>(st, i, P);
+    load_P_any<T>(st, i, P, COMPACT);
     if (filter_uninitialised(x)) return;
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
@@ -835,7 +897,7 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
     T obs[7];
     ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
     store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_rec<T, kSW, kXW, kPW>(st, i, P);
+    store_P_any<T>(st, i, P, COMPACT);
     if (aux_obs) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];
@@ -880,7 +942,7 @@ __global__ void k_unpack_z_off(const T* __restrict__ src, double* __restrict__ z
 }
 // Full n x n row-major covariance -> packed symmetric part (P + P^T)/2 of the state record.
 template <typename T>
-__global__ void k_pack_P_off(const double* __restrict__ Pf, int n, T* __restrict__ st, int64_t i0, int64_t m)
+__global__ void k_pack_P_off(const double* __restrict__ Pf, int n, T* __restrict__ st, int64_t i0, int64_t m, int compact)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= m) return;
@@ -888,17 +950,32 @@ __global__ void k_pack_P_off(const double* __restrict__ Pf, int n, T* __restrict
     for (int a = 0; a < 15; ++a)
         for (int b = a; b < 15; ++b) {
             double v = (a < n && b < n) ? 0.5 * (Pi[a * n + b] + Pi[b * n + a]) : 0.0;
-            st[word_off<T>(kXW + sidx(a, b), i0 + li, kSW)] = (T)v;
+            const int w = p_word(a, b, compact != 0);
+            if (w >= 0) st[word_off<T>(w, i0 + li, kSW)] = (T)v;
         }
 }
 template <typename T>
-__global__ void k_unpack_P_off(const T* __restrict__ st, int n, double* __restrict__ Pf, int64_t i0, int64_t m)
+__global__ void k_unpack_P_off(const T* __restrict__ st, int n, double* __restrict__ Pf, int64_t i0, int64_t m, int compact)
 {
     const int64_t li = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (li >= m) return;
     double* Pi = Pf + li * n * n;
     for (int a = 0; a < n; ++a)
-        for (int b = 0; b < n; ++b) Pi[a * n + b] = (double)st[word_off<T>(kXW + sidx(a, b), i0 + li, kSW)];
+        for (int b = 0; b < n; ++b) {
+            const int w = a <= b ? p_word(a, b, compact != 0) : p_word(b, a, compact != 0);
+            Pi[a * n + b] = w >= 0 ? (double)st[word_off<T>(w, i0 + li, kSW)] : 0.0;
+        }
+}
+
+// The covariance part of every record from one layout to the other (a handle re-configured with the other est_bias, qle_set_params).
+template <typename T>
+__global__ void k_relayout_P(T* __restrict__ st, int from_compact, int to_compact, int64_t B)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B) return;
+    T P[kPW];
+    load_P_any<T>(st, i, P, from_compact != 0);
+    store_P_any<T>(st, i, P, to_compact != 0);
 }
 
 // initialize_state, EKF.cpp:305-344, one filter per lane, for the filters whose tag record's mask word is set
@@ -940,7 +1017,7 @@ __global__ void k_seed(DevParams<T> p, const T* __restrict__ zs, T* __restrict__
         P[sidx(9 + k, 9 + k)] = cov3; P[sidx(12 + k, 12 + k)] = cov4;
     }
     store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_rec<T, kSW, kXW, kPW>(st, i, P);
+    store_P_any<T>(st, i, P, p.compact != 0);
     if (fresh && last_corr) last_corr[i] = tick - 1;
     if (hist_first) {   // multirate: the history is the single entry "state now" (EKF.cpp:337-339)
         hist_first[i] = tick - 1;
@@ -963,7 +1040,8 @@ __global__ void k_report_off(DevParams<T> p, const T* __restrict__ st, const T* 
     {  // rows/cols {0-2, 6-8}, row-major (NODE.cpp:203-210)
         const int sel[6] = {0, 1, 2, 6, 7, 8};
         for (int a = 0; a < 6; ++a)
-            for (int b = 0; b < 6; ++b) pose_cov[li * 36 + a * 6 + b] = X(kXW + sidx(sel[a], sel[b]));
+            for (int b = 0; b < 6; ++b)
+                pose_cov[li * 36 + a * 6 + b] = X(sel[a] <= sel[b] ? p_word(sel[a], sel[b], p.compact != 0) : p_word(sel[b], sel[a], p.compact != 0));
     }
     for (int k = 0; k < 3; ++k) vel[li * 3 + k] = X(3 + k);
     for (int k = 0; k < 3; ++k) {  // ab_nom + ab_static, wb_nom + wb_static (NODE.cpp:215-220)

@@ -52,6 +52,7 @@ static int launch_update_d(qle_batch* h, const void* z)
 template <typename T>
 int launch_update(qle_batch* h, const void* z)
 {
+    if (h->compact) return launch_update_compact<T>(h, z);
     return h->pub.direct_orien_method ? launch_update_d<T, true>(h, z) : launch_update_d<T, false>(h, z);
 }
 
@@ -61,6 +62,7 @@ int launch_update(qle_batch* h, const void* z)
 template <typename T>
 int run_resident_t(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
 {
+    if (h->compact) return run_resident_compact<T>(h, in, t0, n);
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
     const T* pfp = (const T*)h->pfp;

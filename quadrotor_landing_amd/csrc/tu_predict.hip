@@ -11,6 +11,7 @@
 template <typename T>
 int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, bool history)
 {
+    if (h->compact) return launch_predict_compact<T>(h, u, src, dst);   // never with the multirate history
     const DevParams<T>& p = dev<T>(h);
     const dim3 g = grid_for(h, h->block), b(h->block);
     T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;

@@ -27,6 +27,7 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
 template <typename T>
 int launch_step_lane(qle_batch* h, const void* u, const void* z)
 {
+    if (h->compact) return launch_step_compact<T>(h, u, z);
     if (h->pub.direct_orien_method) return h->gating ? launch_step_dg<T, true, true>(h, u, z) : launch_step_dg<T, true, false>(h, u, z);
     return h->gating ? launch_step_dg<T, false, true>(h, u, z) : launch_step_dg<T, false, false>(h, u, z);
 }
