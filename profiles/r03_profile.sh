@@ -4,7 +4,8 @@
 # FETCH_SIZE / WRITE_SIZE passes (separate --pmc runs, --kernel-trace only) at 65 536 filters, at 2 097 152 filters, for cfg 2 and for the
 # multirate predict tick (-> traffic.json, read by the bench lines that follow), bench lines of every workload, rocprofv3 kernel stats
 # of the headline command, of the HBM-resident batch, of cfg 2, of the multirate workload and of fp64, the batch sweep, the per-kernel
-# launch times, the per-wave timelines of the diagnostic build, the pk_fma issue microbenchmark, the accuracy table.
+# launch times, the per-wave timelines of the diagnostic build, the pk_fma issue microbenchmark, the ticks after a multirate correction,
+# compact records against full records, the accuracy table.
 # Raw CSVs stay under gpurun_out/ (scratch); the summaries go to profiles/ via gpurun_out/r3/profiles_out/ (copied back by hand).
 export QLE_HEAD_SHA=${1:-unknown}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
@@ -97,6 +98,15 @@ QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/
 QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/r03_scripts/kw_timeline.py 4096 f64 > $O/r03_kw_timeline.log 2>&1
 timeout -k 10 120 profiles/micro/pk_issue > $O/r03_pk_issue.log 2>&1
 tail -3 $O/r03_mr_timeline.log $O/r03_kw_timeline.log
+
+step "what the ticks after a multirate correction cost (durations by distance from the correcting tick, from the kernel trace above)"
+$py profiles/r03_scripts/after_step.py $R/stats_multirate k_step_mr > $O/r03_after_step.md 2>&1; cat $O/r03_after_step.md
+
+step "compact records (est_bias = false): launch times against full records, FETCH_SIZE / WRITE_SIZE of the compact ticks"
+bash profiles/r03_scripts/compact.sh $QLE_HEAD_SHA compact_final > $R/compact.log 2>&1
+cp gpurun_out/r3/compact_final/times.jsonl $O/r03_compact_times.jsonl
+cp gpurun_out/r3/compact_final/traffic_compact.json $O/r03_compact_traffic.json
+cut -c1-220 $O/r03_compact_times.jsonl
 
 step accuracy
 timeout -k 10 300 $py profiles/measure_accuracy.py > $O/r03_accuracy.md 2> $R/acc.err || tail -5 $R/acc.err
