@@ -23,17 +23,17 @@ pmc() {  # tag counter args...
 }
 pmc fetch_b65536 FETCH_SIZE --steps 280 --kernel-steps 200
 pmc write_b65536 WRITE_SIZE --steps 280 --kernel-steps 200
-$py profiles/summarize.py --traffic $R/pmc_fetch_b65536 $R/pmc_write_b65536 cfg3:65536:f32:predict 'k_predict<float, false, 2, false>' $O/traffic.json
+$py profiles/summarize.py --traffic $R/pmc_fetch_b65536 $R/pmc_write_b65536 cfg3:65536:f32:predict 'k_predict<float, false, 2, false,' $O/traffic.json
 $py profiles/summarize.py --traffic $R/pmc_fetch_b65536 $R/pmc_write_b65536 cfg3:65536:f32:step 'k_step<float' $O/traffic.json
 pmc fetch_b2097152 FETCH_SIZE --batch-per-gpu 2097152 --steps 56 --warmup 14 --kernel-steps 40
 pmc write_b2097152 WRITE_SIZE --batch-per-gpu 2097152 --steps 56 --warmup 14 --kernel-steps 40
-$py profiles/summarize.py --traffic $R/pmc_fetch_b2097152 $R/pmc_write_b2097152 cfg3:2097152:f32:predict 'k_predict<float, false, 3, false>' $O/traffic.json
+$py profiles/summarize.py --traffic $R/pmc_fetch_b2097152 $R/pmc_write_b2097152 cfg3:2097152:f32:predict 'k_predict<float, false, 3, false,' $O/traffic.json
 pmc fetch_cfg2 FETCH_SIZE --workload cfg2 --steps 200 --kernel-steps 200
 pmc write_cfg2 WRITE_SIZE --workload cfg2 --steps 200 --kernel-steps 200
 $py profiles/summarize.py --traffic $R/pmc_fetch_cfg2 $R/pmc_write_cfg2 cfg2:4096:f64:step 'kw_tick<double' $O/traffic.json
 pmc fetch_mr FETCH_SIZE --workload cfg3mr --steps 280 --kernel-steps 200
 pmc write_mr WRITE_SIZE --workload cfg3mr --steps 280 --kernel-steps 200
-$py profiles/summarize.py --traffic $R/pmc_fetch_mr $R/pmc_write_mr cfg3mr:65536:f32:predict 'k_predict<float, false, 2, true>' $O/traffic.json
+$py profiles/summarize.py --traffic $R/pmc_fetch_mr $R/pmc_write_mr cfg3mr:65536:f32:predict 'k_predict<float, false, 2, true,' $O/traffic.json
 $py profiles/summarize.py --traffic $R/pmc_fetch_mr $R/pmc_write_mr cfg3mr:65536:f32:step 'k_step_mr<float' $O/traffic.json
 cp $O/traffic.json profiles/traffic.json   # the bench lines below read it (roofline.traffic)
 
