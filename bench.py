@@ -339,10 +339,11 @@ def main():
     bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * ekf.algorithmic_bytes(1)
     wsz = 4 if args.dtype == "f32" else 8
     if mr_step:
-        # multirate correction tick per filter (k_step_mr, checkpointed history): read u6 + z8 + the checkpoint / anchor the replay
-        # starts from (136) + the stored IMU samples of the replayed ticks (8 words each, step + (k-1)/2 on average, k = 16);
-        # write the anchor (136), the state (136), its IMU sample (8) and the checkpoints passed on the way (136 x step / k)
-        words = (6 + 8 + 136 + 8 * (mr_step + 7)) + (136 + 136 + 8 + 136 * mr_step // 16)
+        # multirate correction per filter and measurement cycle (k_step_mr, checkpointed history): read u6 + z8 + the record the replay
+        # starts from (136: the extra checkpoint a predict tick wrote at the expected entry of this tag pose, so nothing is replayed in
+        # front of the correction) + the stored IMU samples of the replayed ticks (8 words each); write the anchor (136), the state
+        # (136), its IMU sample (8), the grid checkpoints passed on the way (136 x step / k, k = 32) -- and that extra checkpoint (136)
+        words = (6 + 8 + 136 + 8 * mr_step) + (136 + 136 + 8 + 136 * mr_step // 32) + 136
         bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * words * wsz * B
     bad = ekf.count_nonfinite()
     # per-device error sums vs the generator's truth (cfg 5 reduction).  The truth is the pose after ONE pass over the resident

@@ -312,7 +312,9 @@ extern "C" int64_t qle_algorithmic_bytes(const qle_batch* h, int32_t kind)
     if (h->pfp_on) words += kFW;
     int64_t bytes = words * (int64_t)h->wsz * h->B;
     // a multirate predict tick also appends to the history: the IMU sample (6 words + 2 pad) and, every mr_k-th tick, a checkpoint
-    if (h->mr && kind == 0) bytes += (int64_t)((kHW + 136.0 / h->mr_k + (h->e_period > 0 ? 136.0 / (double)h->e_period : 0.0)) * (double)h->wsz * (double)h->B);
+    // (the extra checkpoint at the expected entry of the next tag pose, one more record per measurement cycle, belongs to the correcting
+    // tick's account: bench.py)
+    if (h->mr && kind == 0) bytes += (int64_t)((kHW + 136.0 / h->mr_k) * (double)h->wsz * (double)h->B);
     return bytes;
 }
 
@@ -521,7 +523,6 @@ int mr_prepare(qle_batch* h)
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(h->mr_anchor, state_cur(h), slot_bytes(h), hipMemcpyDeviceToDevice, h->stream));
         h->e_tick = h->e_want = h->last_mr_launch = -1;
-        h->e_period = 0;
     }
     h->hist_dirty = false;
     return QLE_OK;

@@ -31,8 +31,9 @@
 // Registers (csrc/resources.py): the DIRECT orientation method (EKF.cpp:441; both shipped configurations and every BASELINE config)
 // needs no scratch in either dtype.  The CONVENTIONAL method (direct_orien_method = false, EKF.cpp:443-444, the constructor's default)
 // carries Gx through the sweep and does spill: fp32 0-40 B per lane, fp64 140-236 B per lane (256 VGPR + 256 AGPR).  Measured at
-// 65 536 filters with every filter correcting (profiles/r03_kernel_times.jsonl, QLE_TIME_DIRECT=0): fp32 12.85 us against 11.75 us
-// direct, fp64 33.0 us against 25.5 us.  Compact records (est_bias = false) have none in either method.
+// 65 536 filters with every filter correcting (profiles/r03_kernel_times.jsonl, HIP-event period of back-to-back launches,
+// QLE_TIME_DIRECT=0): fp32 12.75 us, the same as the direct method; fp64 32.8 us against 26.8 us.  Compact records (est_bias = false)
+// have none in either method.
 #pragma once
 
 #include <type_traits>

@@ -97,7 +97,6 @@ struct qle_batch {
     int64_t e_tick = -1;           // tick whose state the slot holds, -1 = none
     int64_t e_want = -1;           // the predict launch of this tick fills it, -1 = none scheduled
     int64_t last_mr_launch = -1;   // tick of the last launch of k_step_mr (the cadence of the tag poses as the host sees it)
-    int64_t e_period = 0;          // that cadence in ticks while the extra checkpoint is being scheduled, else 0 (byte accounting)
     double* stamp = nullptr;       // [B] apriltag_time per filter (dynamic delay)
     double* delay_cur = nullptr;   // [B] measurement_delay_curr (EKF.hpp:86)
     double t_curr = 0.0, uniform_age = 0.0;
@@ -247,7 +246,6 @@ static inline void mr_schedule_extra(qle_batch* h)
     // only an entry that lies AFTER this tick is worth a copy (a longer delay than the cadence puts it inside the replayed range,
     // one tick after the anchor), and only while the cadence is short enough for the IMU ring to still hold the samples
     h->e_want = (e > n && period > 1 && period + step < h->mr_Cu) ? e : -1;
-    h->e_period = h->e_want >= 0 ? period : 0;
 }
 
 // ---- kernel launchers, defined and explicitly instantiated for float and double in the tu_*.hip files ----
