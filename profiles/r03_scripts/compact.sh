@@ -7,6 +7,7 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r3/${2:-compact}; mkdir -p $O
 export QLE_TIME_EST_BIAS=0
 : > $O/times.jsonl
+QLE_COMPACT=0 timeout -k 10 200 python3 profiles/time_kernels.py 65536 f32 warmup > /dev/null 2>> $O/err.log   # first process on a fresh box: clocks still ramping
 for B in 65536 262144 1048576; do for c in 0 1; do
   QLE_COMPACT=$c timeout -k 10 200 python3 profiles/time_kernels.py $B f32 compact$c >> $O/times.jsonl 2>> $O/err.log
 done; done

@@ -111,8 +111,9 @@ def test_update_teacher_forced(branch, dtype, tol):
     xg, Pg = ekf.get_state()
     obs = ekf.get_aux()[1]
     xr, Pr, obr = oracle_update_batch(po, x, P, z, mask)
-    # the update divides by the pivots of S: cond(S) more digits go than in a predict (UPD)
-    assert_state_close(xg, Pg, xr, Pr, **UPD[dtype])
+    # the update divides by the pivots of S: cond(S) more digits go than in a predict (UPD); on these states the stand-alone update
+    # measures 6.8e-6 on the covariance in fp32 (the fused tick's 3.3e-5 comes from its predicted covariances)
+    assert_state_close(xg, Pg, xr, Pr, **dict(UPD[dtype], ptol=UPD[dtype]["ptol"] if dtype == "f64" else 7e-5))
     m = mask.astype(bool)
     ot = 1e-12 if dtype == "f64" else 1e-5       # reported observation (measured 1.2e-6 / 1e-7 in fp32)
     note("obs", np.abs(obs[m, :3] - obr[m, :3]).max(), ot)
@@ -1019,7 +1020,7 @@ def test_hardware_like_filter_update_against_twin_golden(mode, delay, dtype):
     rep = lambda a: np.repeat(np.asarray(a)[None], B, 0)
     ekf.initialize_state(rep(d[f"{mode}__z0"]), reinit_bias=True)
     pending = np.zeros(B, np.uint8); zlast = rep(d[f"{mode}__z0"]); stamp = 0.0
-    tol, qtol, ptol = (1e-8, 1e-8, 1e-7) if dtype == "f64" else (2e-5, 1e-6, 4e-4)     # fp32, 240 ticks: measured 2e-6 / 1e-7 / 4.1e-5
+    tol, qtol, ptol = (1e-8, 1e-8, 1e-7) if dtype == "f64" else (2e-5, 1e-6, 6e-5)     # fp32, 240 ticks: measured 2e-6 / 1e-7 / 5.5e-6
     for t in range(U.shape[0]):
         tc = 0.01 * t
         if NEW[t]:

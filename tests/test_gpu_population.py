@@ -198,7 +198,7 @@ def test_filters_initialise_on_their_own_first_detection(dtype, multirate, kerne
             if dtype == "f64":
                 assert_state_close(xg[inited], Pg[inited], xr, Pr, 1e-9, 1e-11, 1e-9)
             else:
-                assert_state_close(xg[inited], Pg[inited], xr, Pr, 6e-5, 6e-5, 8e-6, ptol=2e-4)
+                assert_state_close(xg[inited], Pg[inited], xr, Pr, 2e-5, 2e-5, 2e-6, ptol=2e-4)   # measured 1.6e-6 / 1.5e-7 / 1.9e-5
     assert inited.sum() == B - 4 and n_perf > B
     ekf.close()
 

@@ -102,13 +102,15 @@ def _compare(tr, ref, tol, multirate):
     assert np.array_equal(tr[:, 20], ref[:, 20]) and np.array_equal(tr[:, 21], ref[:, 21])   # same decisions on every tick
     q, qr = tr[:, 7:11], ref[:, 7:11]
     sgn = np.sign(np.sum(q * qr, axis=1, keepdims=True))
-    note("quat", np.abs(q * sgn - qr).max(), tol)
-    np.testing.assert_allclose(q * sgn, qr, rtol=0, atol=tol)
+    qtol = tol if tol < 1e-6 else tol / 10      # fp32: the quaternion is an order of magnitude tighter than the rest (measured 2.9e-7)
+    note("quat", np.abs(q * sgn - qr).max(), qtol)
+    np.testing.assert_allclose(q * sgn, qr, rtol=0, atol=qtol)
     for cols in (slice(1, 7), slice(11, 20)):
         note("state", (np.abs(tr[:, cols] - ref[:, cols]) / (1 + np.abs(ref[:, cols]))).max(), tol)
         np.testing.assert_allclose(tr[:, cols], ref[:, cols], rtol=tol, atol=tol)
-    note("Pdiag", np.abs(tr[:, 23:25] / ref[:, 23:25] - 1).max(), max(tol * 10, 1e-9))
-    np.testing.assert_allclose(tr[:, 23:25], ref[:, 23:25], rtol=max(tol * 10, 1e-9), atol=0)
+    ptol = max(tol * 5, 1e-9)                   # fp32: 1.5e-4 (measured 1.4e-5 single-rate, 1.5-3.5e-6 multirate)
+    note("Pdiag", np.abs(tr[:, 23:25] / ref[:, 23:25] - 1).max(), ptol)
+    np.testing.assert_allclose(tr[:, 23:25], ref[:, 23:25], rtol=ptol, atol=0)
     if multirate:                                              # measurement_delay_curr is only set by the multirate branch (EKF.cpp:199)
         perf = ref[:, 20] > 0
         np.testing.assert_allclose(tr[perf, 22], ref[perf, 22], rtol=0, atol=1e-12)
