@@ -129,7 +129,8 @@ def cpu_baseline(seq, x0, P0, n_filters, n_ticks):
     oracle.run_batch(po, x0[:n1], P0[:n1], U[:, :n1], Z[:, :n1], M[:, :n1], n_threads=1)
     dt_one = time.perf_counter() - t0
     # second, stronger baseline: the engine's own block-structured arithmetic compiled for the host (fp32, all threads)
-    t0 = time.perf_counter()
+    oracle.structured_run_batch(po, x0[:64], P0[:64], U[:2, :64], Z[:2, :64], M[:2, :64], dtype="f32", levels=True, n_threads=1)   # loads (and, if
+    t0 = time.perf_counter()                                                           # stale, rebuilds) the checker library outside the timed call
     oracle.structured_run_batch(po, x0[:n_filters], P0[:n_filters], U, Z, M, dtype="f32", levels=True, n_threads=nthr)
     dt_struct = time.perf_counter() - t0
     return {"value": n_filters * n_ticks / dt_all, "unit": "EKF ticks/s", "cores": nthr, "kind": "port",
