@@ -713,11 +713,45 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     const int32_t t_lo = wave_min_i32(valid ? start : 0x7fffffff);
     if (t_lo == 0x7fffffff) return;            // no initialised filter in this wave (wave-uniform)
     QLE_STAMP(2, (T)start);
+    // The correction of one lane at the entry its measurement belongs to (EKF.cpp:202-211): fuse, then the corrected entry is the anchor.
+    auto correct = [&](T (&P)[kPW]) {
+        T z[7];
+        if constexpr (sizeof(T) == 8) {   // fp64: the tag pose is read again here instead of occupying 16 registers through the pre-replay
+            T zq[kZW];
+            load_rec<T, kZW, 0, kZW>(zs, i, zq);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) z[k] = zq[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) z[k] = zr[k];
+        }
+        auto emit = [&](const T (&o)[7]) {                // EKF.cpp:209
+            if (aux_accel) {
+#pragma unroll
+                for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
+            }
+        };
+        ekf_update_emit<T, DIRECT>(p, nz, x, P, z, emit);
+        store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
+        store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
+    };
     MrChain<T> S;
+    // fp32, regular cadence: every lane's chain starts AT its measurement's entry (the extra checkpoint).  The correction then runs on the
+    // loaded triangle directly -- its scalar chains (innovation, R_k) under the tail of the 36 MB load, no pack / unpack round trip through
+    // the register blocks in front of it -- and the loop below finds nothing left to correct (wave-uniform choice).
+    bool early = false;
     {
         T P[kPW];
         if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
         load_rec<T, kSW, kXW, kPW>(sp, i, P);
+        if constexpr (sizeof(T) == 4) {
+            early = __ballot(valid && !(corr && start == mt)) == 0;
+            if (early && corr) {
+                QLE_STAMP(5, x[0]);
+                correct(P);
+                QLE_STAMP(6, x[0]);
+            }
+        }
         S.from_flat(P);
         QLE_STAMP(3, P[0] + P[119] + x[0]);
     }
@@ -736,29 +770,9 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     int dbg_j = 0;
     (void)dbg_j;
     for (int32_t t = t_lo;;) {                 // t is wave-uniform
-        if (corr && t == mt) {                                // the entry the measurement belongs to
+        if (!early && corr && t == mt) {                      // the entry the measurement belongs to
             QLE_STAMP(5, x[0]);
-            T z[7];
-            if constexpr (sizeof(T) == 8) {   // fp64: the tag pose is read again here instead of occupying 16 registers through the pre-replay
-                T zq[kZW];
-                load_rec<T, kZW, 0, kZW>(zs, i, zq);
-#pragma unroll
-                for (int k = 0; k < 7; ++k) z[k] = zq[k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) z[k] = zr[k];
-            }
-            S.template with_flat<true>([&](T (&P)[kPW]) {
-                auto emit = [&](const T (&o)[7]) {                // EKF.cpp:209
-                    if (aux_accel) {
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
-                    }
-                };
-                ekf_update_emit<T, DIRECT>(p, nz, x, P, z, emit);
-                store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
-                store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
-            });
+            S.template with_flat<true>(correct);
             QLE_STAMP(6, x[0]);
         }
         if (t == m.tick) break;
