@@ -767,13 +767,18 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
 #pragma unroll
         for (int k = 0; k < kUW; ++k) un[k] = u[k];
     }
+    // The chain.  Two copies of the loop, chosen wave-uniformly: without the in-loop correction (`early`) nothing of the correction -- the
+    // tag pose, R -- is live across the replayed ticks, which is what the 256-VGPR kernel is short of.
+    auto chain = [&](auto corr_in_loop) {
     int dbg_j = 0;
     (void)dbg_j;
     for (int32_t t = t_lo;;) {                 // t is wave-uniform
-        if (!early && corr && t == mt) {                      // the entry the measurement belongs to
-            QLE_STAMP(5, x[0]);
-            S.template with_flat<true>(correct);
-            QLE_STAMP(6, x[0]);
+        if constexpr (decltype(corr_in_loop)::value) {
+            if (corr && t == mt) {                            // the entry the measurement belongs to
+                QLE_STAMP(5, x[0]);
+                S.template with_flat<true>(correct);
+                QLE_STAMP(6, x[0]);
+            }
         }
         if (t == m.tick) break;
         ++t;                                                  // EKF.cpp:222-226, then :249
@@ -813,6 +818,13 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
 #ifdef QLE_MR_STAMPS
         ++dbg_j;
 #endif
+    }
+    };
+    if constexpr (sizeof(T) == 4) {
+        if (early) chain(std::false_type{});
+        else chain(std::true_type{});
+    } else {
+        chain(std::true_type{});
     }
     QLE_STAMP(7, x[0]);
     if (aux_accel && valid) {
