@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the environment switches / variant libraries this script drives belonged to an experiment build that is not in the tree
+# (what was changed is described in profiles/r03_tuning.md section 3; its log is under profiles/r03_logs/).
 # cache policy of the anchor stores of k_step_mr (QLE_ANCHOR_CACHED=1: cached stores, so that the anchor slot stays in the Infinity Cache
 # next to the state and the extra checkpoint and its rewrite every cycle never reaches HBM)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

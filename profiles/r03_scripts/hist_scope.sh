@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the environment switches / variant libraries this script drives belonged to an experiment build that is not in the tree
+# (what was changed is described in profiles/r03_tuning.md section 3; its log is under profiles/r03_logs/).
 # explicit scope bits on the stores of the multirate history (experiment builds libqle_v<N>.so: make OBJDIR=build_vN OUT=../libqle_vN.so
 # EXTRA=-DQLE_HIST_SCOPE=N; 1 "sc0 sc1 nt", 2 "sc1", 3 "sc0 sc1", 4 "nt sc1"): bench line, kernel stats, ticks after the correcting tick
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

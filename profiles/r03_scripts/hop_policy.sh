@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the environment switches / variant libraries this script drives belonged to an experiment build that is not in the tree
+# (what was changed is described in profiles/r03_tuning.md section 3; its log is under profiles/r03_logs/).
 # zero-copy checkpoints: cache policy of the tick that writes the state into a checkpoint slot (QLE_HOP_CACHED: cached stores) and of the
 # tick that brings it home (QLE_HOP_BACK: cached stores)
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT

@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the environment switches / variant libraries this script drives belonged to an experiment build that is not in the tree
+# (what was changed is described in profiles/r03_tuning.md section 3; its log is under profiles/r03_logs/).
 # what the ticks after a correcting multirate tick cost, by cache policy of the extra checkpoint (QLE_CK_CACHED) and of the state accesses of
 # k_step_mr (QLE_MR_NT): kernel stats + duration by distance from the correcting tick
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
