@@ -108,6 +108,11 @@ cp gpurun_out/r3/compact_final/times.jsonl $O/r03_compact_times.jsonl
 cp gpurun_out/r3/compact_final/traffic_compact.json $O/r03_compact_traffic.json
 cut -c1-220 $O/r03_compact_times.jsonl
 
+step "small batches: workgroup size of the lane kernels, kernel family by batch size"
+bash profiles/r03_scripts/small_block.sh > $O/r03_small_block.log 2>&1
+bash profiles/r03_scripts/small_family.sh > $O/r03_small_family.log 2>&1
+tail -4 $O/r03_small_family.log
+
 step accuracy
 timeout -k 10 300 $py profiles/measure_accuracy.py > $O/r03_accuracy.md 2> $R/acc.err || tail -5 $R/acc.err
 ls -la $O

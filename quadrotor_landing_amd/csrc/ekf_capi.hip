@@ -261,7 +261,11 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // only for ticks with tag poses (predict-only ticks take the same time on both).  QLE_QUAD=bits overrides (1: ticks with tag
     // poses, 2: predict-only ticks, 0: never).
     // up to 4 096 filters (quarter-tile workgroups, one per CU) it also takes the predict-only ticks: 6.3 against 7.75 us at 4 096 fp64
-    h->quad = batch <= 4096 ? 3 : (batch <= 16384 ? 1 : 0);
+    // Round 3, with one-wave workgroups for the lane-per-filter kernels below 65 536 filters (h->block below): the cooperative kernel
+    // keeps the ticks with tag poses up to 4 096 filters (fp64 9.7 against 11.3 us, fp32 6.4 against 7.25) and the fp64 predict-only ticks
+    // there (5.56 against 5.74); from 8 192 filters on the lane kernels win every tick kind in both dtypes (8 192 fp64: 11.9 against 12.5 us
+    // with tag poses, 6.3 against 8.05 predict-only; 16 384: 13.25 / 14.3, 7.5 / 9.3) -- profiles/r03_logs/small_family.log.
+    h->quad = batch <= 4096 ? (dtype == QLE_F64 ? 3 : 1) : 0;
     if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
     // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
     // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16
@@ -271,9 +275,11 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
         const long long v = std::atoll(s);
         if (v >= 16) h->rebase_at = v;
     }
-    // Workgroup size of the hot kernels: 256 threads (4 tiles) up to 131 072 filters; one wave per workgroup beyond
-    // (finer dispatch: +2-3 % at 262 144 and 524 288 filters, +1.5 % at 1-2 M, level below; profiles/r01_tuning.md section 4).
-    h->block = batch >= 262144 ? 64 : kBlock;
+    // Workgroup size of the lane-per-filter kernels: 256 threads (4 tiles) at 65 536 and 131 072 filters; one wave per workgroup from
+    // 262 144 filters on (finer dispatch: +2-3 % at 262 144 and 524 288 filters, +1.5 % at 1-2 M; profiles/r01_tuning.md section 4) and
+    // BELOW 65 536 filters, where 256-thread workgroups leave CUs without work (32 768 filters are 128 of them on 256 CUs): predict tick
+    // 7.2 -> 6.5 us at 32 768 fp32 filters, 6.0 -> 4.95 at 16 384, fp64 9.5 -> 7.55 at 16 384 (profiles/r03_tuning.md section 7).
+    h->block = (batch >= 262144 || batch < 65536) ? 64 : kBlock;
     if (const char* s = std::getenv("QLE_BLOCK")) {
         int b = std::atoi(s);
         if (b == 64 || b == 128 || b == 256) h->block = b;

@@ -4,7 +4,7 @@ A filter that does not estimate the biases has identically zero bias blocks in P
 serve, its record then keeps only the 45 words of the 9 x 9 pose block (ekf_kernels.hpp, `load_P_compact`) and a tick moves
 16 + 48 words per direction instead of 136.  The arithmetic is the same register image either way, so a compact handle must agree
 with a full-record handle BIT FOR BIT, and with the reference twin's `nobias` goldens within the usual tolerances.
-QLE_COMPACT=1 forces the layout at the small batch sizes of these tests (by default it is chosen from 32 768 filters up).
+QLE_COMPACT=1 forces the layout at the small batch sizes of these tests (by default it is chosen wherever the lane-per-filter kernels serve every tick: above 4 096 filters).
 """
 import numpy as np
 import pytest
@@ -130,10 +130,10 @@ def test_changing_est_bias_on_a_live_handle_converts_the_records(monkeypatch):
     ekf.close()
 
 
-def test_default_rule_picks_compact_records_from_32768_filters(monkeypatch):
+def test_default_rule_picks_compact_records_above_4096_filters(monkeypatch):
     monkeypatch.delenv("QLE_COMPACT", raising=False)
     monkeypatch.delenv("QLE_QUAD", raising=False)
-    for B, est_bias, mr, want in ((32768, 0, 0, 64), (32768, 1, 0, 136), (32768, 0, 1, 136), (4096, 0, 0, 136)):
+    for B, est_bias, mr, want in ((32768, 0, 0, 64), (8192, 0, 0, 64), (32768, 1, 0, 136), (32768, 0, 1, 136), (4096, 0, 0, 136)):
         ekf = qla.BatchedRelativePoseEKF(B, "f32", params=qla.make_params(**dict(NOBIAS, est_bias=est_bias, multirate_ekf=mr)))
         assert ekf.policy()["record_words"] == want, (B, est_bias, mr)
         ekf.close()
