@@ -262,10 +262,12 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // poses, 2: predict-only ticks, 0: never).
     // up to 4 096 filters (quarter-tile workgroups, one per CU) it also takes the predict-only ticks: 6.3 against 7.75 us at 4 096 fp64
     // Round 3, with one-wave workgroups for the lane-per-filter kernels below 65 536 filters (h->block below): the cooperative kernel
-    // keeps the ticks with tag poses up to 4 096 filters (fp64 9.7 against 11.3 us, fp32 6.4 against 7.25) and the fp64 predict-only ticks
-    // there (5.56 against 5.74); from 8 192 filters on the lane kernels win every tick kind in both dtypes (8 192 fp64: 11.9 against 12.5 us
-    // with tag poses, 6.3 against 8.05 predict-only; 16 384: 13.25 / 14.3, 7.5 / 9.3) -- profiles/r03_logs/small_family.log.
-    h->quad = batch <= 4096 ? (dtype == QLE_F64 ? 3 : 1) : 0;
+    // keeps every tick up to 4 096 filters (with tag poses: fp64 9.7 against 11.3 us, fp32 6.4 against 7.25; predict-only: fp64 5.56 against
+    // 5.74, fp32 4.45 against 4.1 in kernel time -- but at 4-5 us per tick the host's launch rate is the limit and a schedule that stays on
+    // one kernel family runs faster end to end: cfg 3 at 4 096 fp32 filters 4.75 against 5.05 us per tick); from 8 192 filters on the lane
+    // kernels win every tick kind in both dtypes (8 192 fp64: 11.9 against 12.5 us with tag poses, 6.3 against 8.05 predict-only; 16 384:
+    // 13.25 / 14.3, 7.5 / 9.3) -- profiles/r03_small_family.log.
+    h->quad = batch <= 4096 ? 3 : 0;
     if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
     // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
     // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16

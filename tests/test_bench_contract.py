@@ -54,9 +54,8 @@ def test_bench_json_contract(extra):
     assert d["nonfinite_filters"] == 0
     assert d["repeats"] >= 1 and abs(d["region_ms"]["median"] - d["ms_per_step"] * 42) < 1e-9
     assert rf["served_by"] in ("infinity_cache", "hbm", "split") and abs(rf["frac_of_measured_copy"] - rf["achieved"] / 6290.0) < 1e-12
-    # 4 096 filters: the workgroup-cooperative kernel (quarter-tile workgroups) takes the ticks with tag poses, and in fp64 the predict-only
-    # ticks too; fp32 predict-only ticks run on the lane-per-filter kernel with one-wave workgroups
-    want_kernel = {"": "k_predict<float>", "cfg5": "k_predict<float>+per-filter-params", "cfg3mr": "k_predict<float,MR>",
+    # 4 096 filters: the workgroup-cooperative kernel takes every single-rate tick at this size (quarter-tile workgroups)
+    want_kernel = {"": "kw_tick<float,predict>", "cfg5": "kw_tick<float,predict>", "cfg3mr": "k_predict<float,MR>",
                    "cfg2": "kw_tick<double,step>"}[extra[1] if extra else ""]
     assert rf["kernel"] == want_kernel, rf["kernel"]
     assert sum(rf["mixed_kernels"].values()) == 42
