@@ -592,6 +592,15 @@ static __device__ unsigned long long qle_dbg_clock[kDbgWaves * kDbgSlots];
 #define QLE_STAMPW(wave, writer, k, dep) do { } while (0)
 #endif
 
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int32_t o = __shfl_xor(v, off, 64);
+        v = o > v ? o : v;
+    }
+    return __builtin_amdgcn_readfirstlane(v);
+}
 // Minimum of a value over the 64 lanes of the wave, as a wave-uniform (SGPR) value.  Every lane must be active.
 __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 {
@@ -767,12 +776,14 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
 #pragma unroll
         for (int k = 0; k < kUW; ++k) un[k] = u[k];
     }
-    // The chain.  Two copies of the loop, chosen wave-uniformly: without the in-loop correction (`early`) nothing of the correction -- the
-    // tag pose, R -- is live across the replayed ticks, which is what the 256-VGPR kernel is short of.
-    auto chain = [&](auto corr_in_loop) {
+    // The chain.  Two copies of the loop: the first runs up to the last entry any lane of the wave corrects at (wave-uniform t_cmax) with
+    // the correction inside; the second takes the rest -- after that tick nothing of the correction (the tag pose, R, its temporaries) is
+    // live across the replayed ticks, which is what the 256-VGPR kernel is short of.  On a regular cadence (`early`) the first has nothing to do.
+    int32_t t = t_lo;                          // wave-uniform
     int dbg_j = 0;
     (void)dbg_j;
-    for (int32_t t = t_lo;;) {                 // t is wave-uniform
+    auto chain = [&](auto corr_in_loop, int32_t t_stop) {
+    for (;;) {
         if constexpr (decltype(corr_in_loop)::value) {
             if (corr && t == mt) {                            // the entry the measurement belongs to
                 QLE_STAMP(5, x[0]);
@@ -780,7 +791,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
                 QLE_STAMP(6, x[0]);
             }
         }
-        if (t == m.tick) break;
+        if (t == t_stop) break;
         ++t;                                                  // EKF.cpp:222-226, then :249
         const bool now = t == m.tick;                         // wave-uniform
         T u6[kUW];
@@ -821,10 +832,11 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     }
     };
     if constexpr (sizeof(T) == 4) {
-        if (early) chain(std::false_type{});
-        else chain(std::true_type{});
+        const int32_t t_cmax = early ? (int32_t)0x80000000 : wave_max_i32(corr ? mt : (int32_t)0x80000000);
+        if (t_cmax >= t_lo) chain(std::true_type{}, t_cmax);       // mt >= start >= t_lo for every correcting lane
+        chain(std::false_type{}, m.tick);
     } else {
-        chain(std::true_type{});
+        chain(std::true_type{}, m.tick);
     }
     QLE_STAMP(7, x[0]);
     if (aux_accel && valid) {
