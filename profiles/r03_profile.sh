@@ -97,6 +97,7 @@ step "per-wave timelines, diagnostic build, and the pk_fma microbenchmark"
 QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/r03_scripts/mr_timeline.py 65536 12 > $O/r03_mr_timeline.log 2>&1
 QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/r03_scripts/kw_timeline.py 4096 f64 > $O/r03_kw_timeline.log 2>&1
 timeout -k 10 120 profiles/micro/pk_issue > $O/r03_pk_issue.log 2>&1
+timeout -k 10 60 profiles/micro/store_path > $O/r03_store_path.log 2>&1
 tail -3 $O/r03_mr_timeline.log $O/r03_kw_timeline.log
 
 step "what the ticks after a multirate correction cost (durations by distance from the correcting tick, from the kernel trace above)"
