@@ -3,7 +3,8 @@
 A filter that does not estimate the biases has identically zero bias blocks in P; on the batch sizes the lane-per-filter kernels
 serve, its record then keeps only the 45 words of the 9 x 9 pose block (ekf_kernels.hpp, `load_P_compact`) and a tick moves
 16 + 48 words per direction instead of 136.  The arithmetic is the same register image either way, so a compact handle must agree
-with a full-record handle BIT FOR BIT, and with the reference twin's `nobias` goldens within the usual tolerances.
+with a full-record handle BIT FOR BIT on the tick kernels (the separately compiled on-chip-resident kernel: to rounding in fp32), and with
+the reference twin's `nobias` goldens within the usual tolerances.
 QLE_COMPACT=1 forces the layout at the small batch sizes of these tests (by default it is chosen wherever the lane-per-filter kernels serve every tick: above 4 096 filters).
 """
 import numpy as np
@@ -137,3 +138,54 @@ def test_default_rule_picks_compact_records_above_4096_filters(monkeypatch):
         ekf = qla.BatchedRelativePoseEKF(B, "f32", params=qla.make_params(**dict(NOBIAS, est_bias=est_bias, multirate_ekf=mr)))
         assert ekf.policy()["record_words"] == want, (B, est_bias, mr)
         ekf.close()
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_compact_records_seeding_gating_and_resident_runs_bit_for_bit(dtype, monkeypatch):
+    """The paths the first test does not reach: `initialize_state` (k_seed), the gated `filter_update` tick, device-resident sequences
+    (`run`) and the on-chip-resident variant (`run_resident`) -- compact against full records, bit for bit."""
+    B = 300
+    out = []
+    for compact in (False, True):
+        ekf = _handle(B, dtype, monkeypatch, compact, limit_measurement_freq=1, corner_margin_enbl=1)
+        rng = np.random.default_rng(9)
+        z0 = np.zeros((B, 7)); z0[:, 0:2] = rng.normal(size=(B, 2)) * 0.1; z0[:, 2] = rng.uniform(0.8, 2.0, size=B)
+        z0[:, 3:7] = np.array([0.7071067811865476, -0.7071067811865476, 0.0, 0.0])
+        mask = (np.arange(B) % 5 != 0).astype(np.uint8)        # every fifth filter stays uninitialised
+        ekf.enable_gating(True)
+        ekf.initialize_state(z0, reinit_bias=True, mask=mask)
+        pending = np.zeros(B, np.uint8); zlast = z0.copy()
+        for t in range(30):
+            u = rand_imu(rng, B) * np.array([0.05, 0.05, 1, 0.2, 0.2, 0.2])
+            if t % 3 == 0:
+                xs = ekf.get_state()[0]
+                xs[mask == 0, 9] = 1.0
+                zlast = meas_near(rng, oracle.make_params(**NOBIAS), xs, ang=0.2, pos=0.05)
+                pending[:] = mask
+            ekf.filter_update(u, zlast if pending.any() else None, pending if pending.any() else None)
+            perf, cons, _ = ekf.tick_flags()
+            pending &= (1 - cons)
+        T = 28
+        thm = np.zeros(T, np.uint8); thm[6::7] = 1
+        ekf.enable_gating(False)
+        seq = ekf.make_inputs(T, thm)
+        ekf.synth_generate(seq, seed=4)
+        ekf.initialize_state(z0, reinit_bias=True, mask=mask)   # synth_generate seeds all filters: back to the masked population
+        ekf.run(seq, 0, T)
+        a = ekf.get_state()
+        ekf.run_resident(seq, 0, T)
+        b = ekf.get_state()
+        out.append((a, b))
+        assert np.isfinite(b[0]).all() and np.isfinite(b[1]).all()
+        ekf.close()
+    # The tick kernels (seeding, gated ticks, device-resident sequences): bit for bit in both dtypes.  The on-chip-resident kernel in fp32
+    # agrees to rounding only (1.3e-7 absolute after these 28 ticks): the two instantiations are compiled separately, and once the dead bias
+    # arithmetic is gone the backend fuses some multiply-adds of the in-place predict differently (a product whose second use died becomes
+    # fusable).
+    for which, ((xf, Pf), (xc, Pc)) in zip(("run", "run_resident"), zip(out[0], out[1])):
+        if dtype == "f64" or which == "run":
+            np.testing.assert_array_equal(xc, xf, err_msg=which)
+            np.testing.assert_array_equal(Pc, Pf, err_msg=which)
+        else:
+            np.testing.assert_allclose(xc, xf, rtol=0, atol=2e-6, err_msg=which)
+            np.testing.assert_allclose(Pc, Pf, rtol=0, atol=2e-6, err_msg=which)
