@@ -197,6 +197,25 @@ def sub_record(qla, cfg, B, dtype, upd, n_pred, n_mixed, seed, device):
     return out
 
 
+def self_launch(n, stdout_fd):
+    """Run this script as n ranks (one per GPU) under torch.distributed.run and return the launcher's exit code."""
+    import socket
+    with socket.socket() as s:      # a free rendezvous port on the loopback (the container hostname may not resolve)
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    child = subprocess.Popen(cmd, stdout=stdout_fd, stderr=2, env=env, cwd=os.getcwd())
+    try:
+        return child.wait()
+    except KeyboardInterrupt:
+        child.terminate()       # the launcher we started (exact PID); it takes its ranks down with it
+        return child.wait()
+
+
 def main():
     # stdout carries exactly ONE JSON line (rank 0).  Libraries print there too (gloo announces its peers on
     # stdout), so fd 1 is pointed at stderr for the whole run and the line goes to the saved descriptor.
@@ -246,8 +265,11 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N with N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # plain `python bench.py --gpus N`: start the N ranks ourselves, as fresh child processes under torch.distributed.run, BEFORE
+            # this process makes any GPU call (it never does: it only relays).  The children's rank 0 writes the one JSON line straight to
+            # our stdout; we exit with the launcher's code (non-zero if any rank failed).  Nothing is exec-replaced.
+            sys.exit(self_launch(args.gpus, real_stdout))
         args.gpus = world
     dist = None
     placement = pin_to_gpu_numa_node(local_rank, world) if world > 1 else None   # before the first GPU call of this process

@@ -96,6 +96,41 @@ def test_bench_two_ranks_print_one_json_line():
     _check_per_rank(d, [4096, 4096], [0, 4096])
 
 
+@pytest.mark.gpu
+def test_bench_plain_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` WITHOUT torch.distributed.run (the form of the driver's N = 1 command): the script starts its two
+    ranks itself as fresh child processes, before its own process touches the GPU, and relays rank 0's one JSON line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "42", "--warmup", "14", "--batch-per-gpu", "4096",
+           "--kernel-steps", "60"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 8192 and d["scaling"] == "weak"
+    _check_per_rank(d, [4096, 4096], [0, 4096])
+
+
+def test_bench_plain_command_launch_line_without_a_gpu():
+    """The same self-launch on a machine with no GPU (this container): both ranks must come up under the launcher, fail LOUDLY in
+    qle_create (no CPU fallback), and the parent must hand the launcher's non-zero exit code on -- no JSON line, no hang."""
+    sys.path.insert(0, ROOT)
+    import quadrotor_landing_amd as qla
+    import ctypes
+    n = ctypes.c_int32(0)
+    qla.lib().qle_device_count(ctypes.byref(n))
+    if n.value > 0:
+        pytest.skip("a GPU is present: covered by test_bench_plain_command_starts_its_own_ranks")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2", "--batch-per-gpu", "64"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert r.returncode != 0
+    assert r.stdout.strip() == ""
+    assert "no HIP device" in r.stderr or "QLE_ERR_NO_DEVICE" in r.stderr or "no CPU fallback" in r.stderr, r.stderr[-1500:]
+    assert r.stderr.count("no CPU fallback") + r.stderr.count("no HIP device") >= 2      # both ranks got as far as the engine
+
+
 def _check_per_rank(d, filters, offsets):
     """What every rank saw on its own survives next to the max-over-ranks figure: shard sizes, global filter offsets, per-rank
     wall and HIP-event time per step (the reported ms_per_step is their maximum, region by region), CPU placement."""
