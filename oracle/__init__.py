@@ -69,7 +69,7 @@ def build(force=False):
 def build_structured(force=False):
     csrc = os.path.join(_HERE, "..", "quadrotor_landing_amd", "csrc")
     src = [os.path.join(_HERE, "ekf_structured_cpu.cpp"), os.path.join(_HERE, "Makefile")] + \
-          [os.path.join(csrc, h) for h in ("ekf_device.hpp", "ekf_quad.hpp", "ekf_fused.hpp", "ekf_packed.hpp")]   # the Makefile rule's list
+          [os.path.join(csrc, h) for h in ("ekf_device.hpp", "ekf_quad.hpp", "ekf_fused.hpp", "ekf_packed.hpp", "ekf_split.hpp")]   # the Makefile rule's list
     stale = (not os.path.exists(_LIB_STRUCT)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_STRUCT) for s in src)
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B", "libekf_oracle_structured.so"], check=True)
@@ -116,7 +116,8 @@ def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True
     """The engine's own per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_device.hpp) compiled for the CPU:
     same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product.
     levels: True = levelled predict + sequential update, False = in-place predict, "fused" = the fused tick (ekf_fused.hpp),
-    "packed" = the register-block predict of the multirate replay loop (ekf_packed.hpp) + sequential update."""
+    "packed" = the register-block predict of the multirate replay loop (ekf_packed.hpp) + sequential update,
+    "split" = predict and batch-form correction on the covariance split between LDS rows and registers (ekf_split.hpp, fp64 multirate replay)."""
     _slib = _structured_lib()
     n = p.num_states
     x = np.array(x, dtype=np.float64, order="C").reshape(-1, 16)
@@ -129,7 +130,7 @@ def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True
         z = np.ascontiguousarray(z, dtype=np.float64).reshape(T, B, 7)
         mask = np.ascontiguousarray(mask, dtype=np.uint8).reshape(T, B)
         zp = _p(z); mp = mask.ctypes.data_as(C.POINTER(C.c_uint8))
-    _slib.orc_structured_run_batch(C.byref(p), B, T, _p(x), _p(P), _p(u), zp, mp, 0 if dtype == "f32" else 1, {"fused": 2, "packed": 3}.get(levels, int(bool(levels))), int(n_threads))
+    _slib.orc_structured_run_batch(C.byref(p), B, T, _p(x), _p(P), _p(u), zp, mp, 0 if dtype == "f32" else 1, {"fused": 2, "packed": 3, "split": 4}.get(levels, int(bool(levels))), int(n_threads))
     return x, P.reshape(B, n, n)
 
 

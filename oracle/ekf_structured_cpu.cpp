@@ -20,6 +20,7 @@
 #include "../quadrotor_landing_amd/csrc/ekf_quad.hpp"
 #include "../quadrotor_landing_amd/csrc/ekf_fused.hpp"
 #include "../quadrotor_landing_amd/csrc/ekf_packed.hpp"
+#include "../quadrotor_landing_amd/csrc/ekf_split.hpp"
 #include "ekf_oracle.h"
 
 using namespace qle;
@@ -64,9 +65,24 @@ static int64_t run_batch_t(const orc_params* p, int64_t B, int64_t Tn, double* x
             for (int b = a; b < 15; ++b) Pp[sidx(a, b)] = (a < n && b < n) ? (T)(0.5 * (Pi[a * n + b] + Pi[b * n + a])) : T(0);
         PackedCov<T> Sb;                     // levels == 3: the covariance as register blocks (ekf_packed.hpp), kept across ticks
         if (levels == 3) cov_pack<T>(Pp, Sb);
+        ArrayTop<T> top;                     // levels == 4: the covariance split between "LDS" rows (an array here) and registers (ekf_split.hpp)
+        T lo[kLoWords];
+        if (levels == 4) split_from_flat<T>(Pp, top, lo);
         for (int64_t t = 0; t < Tn; ++t) {
             const double* ut = u + (t * B + i) * 6;
             const T uu[6] = {(T)ut[0], (T)ut[1], (T)ut[2], (T)ut[3], (T)ut[4], (T)ut[5]};
+            if (levels == 4) {   // what the fp64 multirate replay loop runs: predict and batch-form correction on the split covariance
+                ekf_predict_split<T>(dp, nz, xs, top, lo, uu, acc);
+                if (mask && mask[t * B + i]) {
+                    const double* zt = z + (t * B + i) * 7;
+                    const T zz[7] = {(T)zt[0], (T)zt[1], (T)zt[2], (T)zt[3], (T)zt[4], (T)zt[5], (T)zt[6]};
+                    auto none7 = [](const T (&)[7]) {};
+                    if (p->direct_orien_method) ekf_update_split<T, true>(dp, nz, xs, top, lo, zz, none7);
+                    else ekf_update_split<T, false>(dp, nz, xs, top, lo, zz, none7);
+                }
+                if (t + 1 == Tn) split_to_flat<T>(top, lo, Pp);
+                continue;
+            }
             if (levels == 3) {   // what the multirate replay loop runs: packed predict, blocks unpacked only for a correction
                 ekf_predict_packed<T>(dp, nz, xs, Sb, uu, acc);
                 if (mask && mask[t * B + i]) {

@@ -24,6 +24,7 @@
 #include "ekf_quad.hpp"
 #include "ekf_fused.hpp"
 #include "ekf_packed.hpp"
+#include "ekf_split.hpp"
 
 namespace qle {
 
@@ -623,13 +624,27 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
 // lanes starts from, a lane joins at its own entry -- so that the history addresses (IMU ring slot, checkpoint slot) are scalar and
 // the "is this the current tick" selects are scalar branches.  One predict call site serves the replay and the current tick.
 // The covariance of a replayed chain as it is held between the ticks of the loop.  fp32: the register blocks of ekf_packed.hpp (two FMAs per
-// instruction).  fp64: the packed triangle itself, advanced in place by the three congruences of ekf_device.hpp -- fp64 has no packed FMA
-// to gain from the block form and its nine-word diagonal blocks would cost 30 registers the kernel does not have -- with the
-// per-tick scalar part of ekf_packed.hpp (no libm call, F[th,th] from the quaternion the nominal state needs anyway).
+// instruction), the correction on the unpacked triangle.  fp64: SPLIT (ekf_split.hpp) -- the packed triangle alone is 240 of a wave's 512
+// registers and with the correction's gain vectors next to it the kernel spilled 1.2-1.5 KB per lane (240 us per launch); the two top
+// block-rows (75 of the 120 values) live in the wave's 37.5 KiB window of the LDS instead, the three bottom ones in registers, and predict
+// and correction stream the top rows through registers a 3 x 3 block at a time: no scratch.
+extern __shared__ unsigned char qle_dyn_lds[];
+constexpr size_t kMrLdsPerWave = (size_t)kTopWords * kTile * sizeof(double);   // fp64 only (fp32 launches with no dynamic LDS)
 template <typename T, bool BLOCKS = (sizeof(T) == 4)> struct MrChain;
 template <typename T> struct MrChain<T, true> {
     PackedCov<T> S;
+    __device__ __forceinline__ void init() {}
     __device__ __forceinline__ void from_flat(const T (&P)[kPW]) { cov_pack<T>(P, S); }
+    __device__ __forceinline__ void load_cov(const T* __restrict__ src, int64_t i)
+    {
+        T P[kPW];
+        load_rec<T, kSW, kXW, kPW>(src, i, P);
+        from_flat(P);
+    }
+    template <int NT> __device__ __forceinline__ void store_cov(T* __restrict__ dst, int64_t i)
+    {
+        with_flat<false>([&](const T (&P)[kPW]) { store_rec<T, kSW, kXW, kPW, NT>(dst, i, P); });
+    }
     // f(P) on the packed triangle; MODIFIES: f changes P
     template <bool MODIFIES, typename F> __device__ __forceinline__ void with_flat(F&& f)
     {
@@ -642,21 +657,74 @@ template <typename T> struct MrChain<T, true> {
     {
         ekf_predict_packed<T>(p, nz, x, S, u, accel);
     }
+    // correction_step at the entry the measurement belongs to; done(P): the corrected triangle (the new anchor)
+    template <bool DIRECT, typename Emit, typename Done>
+    __device__ __forceinline__ void correct(const DevParams<T>& p, const Noise<T>& nz, T (&x)[kXW], const T (&z)[7], Emit&& emit, Done&& done)
+    {
+        with_flat<true>([&](T (&P)[kPW]) {
+            ekf_update_emit<T, DIRECT>(p, nz, x, P, z, emit);
+            done([&](T* __restrict__ dst, int64_t i) { store_rec<T, kSW, kXW, kPW, 2>(dst, i, P); });
+        });
+    }
     __device__ __forceinline__ T probe() const { return S.blk(2, 2).d + S.blk(0, 1).c.x; }   // values a predict forms last (diagnostic stamps)
 };
 template <typename T> struct MrChain<T, false> {
-    T P[kPW];
-    __device__ __forceinline__ void from_flat(const T (&Pf)[kPW])
+    T lo[kLoWords];
+    LdsTop<T> top;
+    __device__ __forceinline__ void init()
     {
-#pragma unroll
-        for (int k = 0; k < kPW; ++k) P[k] = Pf[k];
+        top.p = reinterpret_cast<T*>(qle_dyn_lds) + (size_t)(threadIdx.x >> 6) * (kTopWords * kTile) + (threadIdx.x & 63);
     }
-    template <bool MODIFIES, typename F> __device__ __forceinline__ void with_flat(F&& f) { f(P); }   // no second copy of P
+    // Record words [W0, W0 + W) of the packed triangle <-> their homes.  The record is moved in two parts with a fence between them
+    // (the first 84 words hold block-rows r and v, which go to the LDS): all 120 words at once would be 240 registers in flight next to
+    // everything else the kernel holds at that point.
+    template <int W0, int W> __device__ __forceinline__ void load_part(const T* __restrict__ src, int64_t i)
+    {
+        T t[W];
+        load_rec<T, kSW, kXW + W0, W>(src, i, t);
+        static_for<W0, W0 + W>([&](auto wc) {   // a compile-time loop: every index must be a constant (no array may reach scratch)
+            constexpr int w = decltype(wc)::value, hw = split_word(word_row(w), word_col(w));
+            if constexpr (word_row(w) < 6) top.st(hw, t[w - W0]);
+            else lo[hw] = t[w - W0];
+        });
+    }
+    template <int NT, int W0, int W> __device__ __forceinline__ void store_part(T* __restrict__ dst, int64_t i)
+    {
+        T t[W];
+        static_for<W0, W0 + W>([&](auto wc) {
+            constexpr int w = decltype(wc)::value, hw = split_word(word_row(w), word_col(w));
+            if constexpr (word_row(w) < 6) t[w - W0] = top.ld(hw);
+            else t[w - W0] = lo[hw];
+        });
+        store_rec<T, kSW, kXW + W0, W, NT>(dst, i, t);
+    }
+    static constexpr int kTopPart = 84;   // words 0..83: block-rows r, v and the first words of row th (sidx order, ekf_device.hpp)
+    __device__ __forceinline__ void load_cov(const T* __restrict__ src, int64_t i)
+    {
+        load_part<0, kTopPart>(src, i);
+        QLE_PHASE_FENCE();
+        load_part<kTopPart, kPW - kTopPart>(src, i);
+        QLE_PHASE_FENCE();
+    }
+    template <int NT> __device__ __forceinline__ void store_cov(T* __restrict__ dst, int64_t i)
+    {
+        QLE_PHASE_FENCE();
+        store_part<NT, 0, kTopPart>(dst, i);
+        QLE_PHASE_FENCE();
+        store_part<NT, kTopPart, kPW - kTopPart>(dst, i);
+        QLE_PHASE_FENCE();
+    }
     __device__ __forceinline__ void predict(const DevParams<T>& p, const Noise<T>& nz, T (&x)[kXW], const T (&u)[kUW], T (&accel)[3])
     {
-        ekf_predict_lean<T>(p, nz, x, P, u, accel);
+        ekf_predict_split<T>(p, nz, x, top, lo, u, accel);
     }
-    __device__ __forceinline__ T probe() const { return P[sidx(8, 8)] + P[sidx(0, 5)]; }
+    template <bool DIRECT, typename Emit, typename Done>
+    __device__ __forceinline__ void correct(const DevParams<T>& p, const Noise<T>& nz, T (&x)[kXW], const T (&z)[7], Emit&& emit, Done&& done)
+    {
+        ekf_update_split<T, DIRECT>(p, nz, x, top, lo, z, emit);
+        done([&](T* __restrict__ dst, int64_t i) { store_cov<2>(dst, i); });
+    }
+    __device__ __forceinline__ T probe() const { return lo[L_TT] + top.ld(T_RV); }
 };
 
 template <typename T, bool DIRECT, bool PFP>
@@ -723,7 +791,19 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     if (t_lo == 0x7fffffff) return;            // no initialised filter in this wave (wave-uniform)
     QLE_STAMP(2, (T)start);
     // The correction of one lane at the entry its measurement belongs to (EKF.cpp:202-211): fuse, then the corrected entry is the anchor.
-    auto correct = [&](T (&P)[kPW]) {
+    auto emit = [&](const T (&o)[7]) {                    // EKF.cpp:209
+        if (aux_accel) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
+        }
+    };
+    auto new_anchor = [&](auto&& store_cov_to) {          // EKF.cpp:210-211: the history now starts here
+        store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);
+        store_cov_to(anchor, i);
+    };
+    MrChain<T> S;
+    S.init();
+    auto correct_chain = [&]() {
         T z[7];
         if constexpr (sizeof(T) == 8) {   // fp64: the tag pose is read again here instead of occupying 16 registers through the pre-replay
             T zq[kZW];
@@ -734,35 +814,30 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
 #pragma unroll
             for (int k = 0; k < 7; ++k) z[k] = zr[k];
         }
-        auto emit = [&](const T (&o)[7]) {                // EKF.cpp:209
-            if (aux_accel) {
-#pragma unroll
-                for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = o[k];
-            }
-        };
-        ekf_update_emit<T, DIRECT>(p, nz, x, P, z, emit);
-        store_rec<T, kSW, 0, kXW, 2>(anchor, i, x);       // EKF.cpp:210-211: the history now starts here
-        store_rec<T, kSW, kXW, kPW, 2>(anchor, i, P);
+        if constexpr (sizeof(T) == 8 && PFP) load_noise<T, PFP>(p, pfp, i, nz);
+        S.template correct<DIRECT>(p, nz, x, z, emit, new_anchor);
     };
-    MrChain<T> S;
     // fp32, regular cadence: every lane's chain starts AT its measurement's entry (the extra checkpoint).  The correction then runs on the
     // loaded triangle directly -- its scalar chains (innovation, R_k) under the tail of the 36 MB load, no pack / unpack round trip through
     // the register blocks in front of it -- and the loop below finds nothing left to correct (wave-uniform choice).
     bool early = false;
-    {
+    if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
+    if constexpr (sizeof(T) == 4) {
         T P[kPW];
-        if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
         load_rec<T, kSW, kXW, kPW>(sp, i, P);
-        if constexpr (sizeof(T) == 4) {
-            early = __ballot(valid && !(corr && start == mt)) == 0;
-            if (early && corr) {
-                QLE_STAMP(5, x[0]);
-                correct(P);
-                QLE_STAMP(6, x[0]);
-            }
+        early = __ballot(valid && !(corr && start == mt)) == 0;
+        if (early && corr) {
+            QLE_STAMP(5, x[0]);
+            const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+            ekf_update_emit<T, DIRECT>(p, nz, x, P, z, emit);
+            new_anchor([&](T* __restrict__ dst, int64_t ii) { store_rec<T, kSW, kXW, kPW, 2>(dst, ii, P); });
+            QLE_STAMP(6, x[0]);
         }
         S.from_flat(P);
         QLE_STAMP(3, P[0] + P[119] + x[0]);
+    } else {
+        S.load_cov(sp, i);
+        QLE_STAMP(3, S.probe() + x[0]);
     }
     // The IMU sample of the NEXT replayed tick is requested one step ahead (wave-uniform slot address).  One step of arithmetic (~1.8 us)
     // covers the latency of the ring, which was streamed to HBM; requesting the whole window up front instead (LDS-DMA into a per-wave LDS
@@ -787,7 +862,7 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         if constexpr (decltype(corr_in_loop)::value) {
             if (corr && t == mt) {                            // the entry the measurement belongs to
                 QLE_STAMP(5, x[0]);
-                S.template with_flat<true>(correct);
+                correct_chain();
                 QLE_STAMP(6, x[0]);
             }
         }
@@ -806,24 +881,39 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
             for (int k = 0; k < kUW; ++k) un[k] = uc[k];
         }
         if (valid && t > start) {
+            if constexpr (sizeof(T) == 8 && PFP) load_noise<T, PFP>(p, pfp, i, nz);   // fp64: 24 values read again (L2) rather than 48 registers held through the loop
             S.predict(p, nz, x, u6, accel);
             QLE_STAMP(9 + 2 * dbg_j, x[0] + x[9] + S.probe());
             const bool extra = t == m.e_tick;                 // wave-uniform
             const bool ck = (t % m.k == 0 || extra) && (now || (corr && t > mt));   // checkpoints of the rewritten part of the chain
-            if (now || ck) {
-                S.template with_flat<false>([&](const T (&P)[kPW]) {
-                    if (now) {
-                        store_rec<T, kSW, 0, kXW>(cur, i, x);
-                        store_rec<T, kSW, kXW, kPW>(cur, i, P);
-                        const T uk[kHW] = {u6[0], u6[1], u6[2], u6[3], u6[4], u6[5], T(0), T(0)};
-                        store_rec<T, kHW, 0, kHW, QLE_RING_POLICY>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
-                    }
-                    if (ck) {
-                        T* ckp = extra ? ckpt + (int64_t)m.Nc * m.slot_words : mr_ck_slot(ckpt, m, t);
-                        store_rec<T, kSW, 0, kXW, 2>(ckp, i, x);
-                        store_rec<T, kSW, kXW, kPW, 2>(ckp, i, P);
-                    }
-                });
+            if constexpr (sizeof(T) == 4) {
+                if (now || ck) {
+                    S.template with_flat<false>([&](const T (&P)[kPW]) {
+                        if (now) {
+                            store_rec<T, kSW, 0, kXW>(cur, i, x);
+                            store_rec<T, kSW, kXW, kPW>(cur, i, P);
+                        }
+                        if (ck) {
+                            T* ckp = extra ? ckpt + (int64_t)m.Nc * m.slot_words : mr_ck_slot(ckpt, m, t);
+                            store_rec<T, kSW, 0, kXW, 2>(ckp, i, x);
+                            store_rec<T, kSW, kXW, kPW, 2>(ckp, i, P);
+                        }
+                    });
+                }
+            } else {
+                if (now) {
+                    store_rec<T, kSW, 0, kXW>(cur, i, x);
+                    S.template store_cov<0>(cur, i);
+                }
+                if (ck) {
+                    T* ckp = extra ? ckpt + (int64_t)m.Nc * m.slot_words : mr_ck_slot(ckpt, m, t);
+                    store_rec<T, kSW, 0, kXW, 2>(ckp, i, x);
+                    S.template store_cov<2>(ckp, i);
+                }
+            }
+            if (now) {
+                const T uk[kHW] = {u6[0], u6[1], u6[2], u6[3], u6[4], u6[5], T(0), T(0)};
+                store_rec<T, kHW, 0, kHW, QLE_RING_POLICY>(mr_u_slot(uring, m, t), i, uk);   // EKF.cpp:254-256
             }
         }
 #ifdef QLE_MR_STAMPS
@@ -831,12 +921,10 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
 #endif
     }
     };
-    if constexpr (sizeof(T) == 4) {
+    {
         const int32_t t_cmax = early ? (int32_t)0x80000000 : wave_max_i32(corr ? mt : (int32_t)0x80000000);
         if (t_cmax >= t_lo) chain(std::true_type{}, t_cmax);       // mt >= start >= t_lo for every correcting lane
         chain(std::false_type{}, m.tick);
-    } else {
-        chain(std::true_type{}, m.tick);
     }
     QLE_STAMP(7, x[0]);
     if (aux_accel && valid) {

@@ -27,10 +27,25 @@ int launch_step_mr(qle_batch* h, const void* u, const void* z)
     T *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
-#define QLE_MR_LAUNCH(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, 0, h->stream, p, gp, m, (T*)state_cur(h), (T*)h->mr_u, (T*)h->mr_ckpt, (T*)h->mr_anchor, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
+    // fp64: the two top block-rows of every filter's covariance live in the LDS for the whole replay (ekf_split.hpp): 37.5 KiB per wave,
+    // 150 KiB of a CU's 160 KiB for a 256-thread workgroup (more than the 64 KiB a launch gets without asking)
+    const size_t lds = sizeof(T) == 8 ? (size_t)(h->block / kTile) * kMrLdsPerWave : 0;
+#define QLE_MR_LAUNCH(D, F)                                                                                                            \
+    do {                                                                                                                               \
+        if (lds > 65536) {                                                                                                             \
+            static bool asked = false;   /* per instantiation; the attribute is a property of the kernel */                           \
+            if (!asked) {                                                                                                              \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_mr<T, D, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+                asked = true;                                                                                                          \
+            }                                                                                                                          \
+        }                                                                                                                              \
+        QLE_MR_LAUNCH1(D, F);                                                                                                          \
+    } while (0)
+#define QLE_MR_LAUNCH1(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, lds, h->stream, p, gp, m, (T*)state_cur(h), (T*)h->mr_u, (T*)h->mr_ckpt, (T*)h->mr_anchor, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
     if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
     else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
 #undef QLE_MR_LAUNCH
+#undef QLE_MR_LAUNCH1
     HIP_TRY(hipGetLastError());
     mr_schedule_extra(h);
     return QLE_OK;

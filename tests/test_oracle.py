@@ -411,7 +411,7 @@ def engine_cpu_run(variant, p, x, P, U, Z, M, dtype):
     emulated quad (ekf_quad.hpp)."""
     if variant == "quad":
         return oracle.quad_run_batch(p, x, P, U, Z, M, dtype=dtype)
-    return oracle.structured_run_batch(p, x, P, U, Z, M, dtype=dtype, levels=variant if variant in ("fused", "packed") else (variant == "levels"))
+    return oracle.structured_run_batch(p, x, P, U, Z, M, dtype=dtype, levels=variant if variant in ("fused", "packed", "split") else (variant == "levels"))
 
 
 def test_packed_covariance_order_is_a_bijection_with_level_structure():
@@ -443,7 +443,7 @@ def test_packed_covariance_order_is_a_bijection_with_level_structure():
         assert min(rows[4 * q: 4 * q + 4]) <= min(rows[4 * q + 4: 4 * q + 8]) or q % 3 != 2
 
 
-@pytest.mark.parametrize("variant", ["levels", "inplace", "quad", "fused", "packed"])
+@pytest.mark.parametrize("variant", ["levels", "inplace", "quad", "fused", "packed", "split"])
 @pytest.mark.parametrize("direct", [0, 1])
 @pytest.mark.parametrize("est_bias", [0, 1])
 def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, est_bias, variant):
@@ -490,7 +490,7 @@ def test_structured_cpu_build_of_engine_arithmetic_matches_dense_oracle(direct, 
 
 
 @pytest.mark.parametrize("ps", PSETS)
-@pytest.mark.parametrize("variant", ["levels", "inplace", "quad", "fused", "packed"])
+@pytest.mark.parametrize("variant", ["levels", "inplace", "quad", "fused", "packed", "split"])
 def test_structured_cpu_build_against_reference_twin_sequences(golden_dir, ps, variant):
     """The engine's arithmetic (CPU build) against the trajectories the reference's Python twin produced."""
     sets = load_param_sets(golden_dir)
