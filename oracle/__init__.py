@@ -112,6 +112,17 @@ def quad_run_batch(p, x, P, u, z=None, mask=None, dtype="f64"):
     return x, P.reshape(B, n, n)
 
 
+def structured_quat_exp(v, dtype="f64"):
+    """The engine's quaternion_exp (ekf_device.hpp compiled for the host) for rotation vectors v [n, 3] -> [n, 4] (x, y, z, w)."""
+    L = _structured_lib()
+    v = np.ascontiguousarray(v, dtype=np.float64).reshape(-1, 3)
+    q = np.empty((v.shape[0], 4))
+    L.orc_structured_quat_exp.argtypes = [C.POINTER(_d), C.POINTER(_d), C.c_int64, _i]
+    L.orc_structured_quat_exp.restype = None
+    L.orc_structured_quat_exp(_p(v), _p(q), v.shape[0], 0 if dtype == "f32" else 1)
+    return q
+
+
 def structured_run_batch(p, x, P, u, z=None, mask=None, dtype="f64", levels=True, n_threads=0):
     """The engine's own per-filter arithmetic (quadrotor_landing_amd/csrc/ekf_device.hpp) compiled for the CPU:
     same contract as run_batch.  Second CPU baseline and no-GPU algebra check; never part of the product.

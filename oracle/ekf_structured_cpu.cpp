@@ -238,6 +238,23 @@ static int64_t quad_run_batch_t(const orc_params* p, int64_t B, int64_t Tn, doub
 }
 
 extern "C" {
+// The engine's quaternion_exp (ekf_device.hpp: half-angle series with halving / doubling beyond pi/4) for n rotation vectors.
+void orc_structured_quat_exp(const double* v, double* q, int64_t n, int dtype)
+{
+    for (int64_t i = 0; i < n; ++i) {
+        if (dtype == 0) {
+            const float vv[3] = {(float)v[3 * i], (float)v[3 * i + 1], (float)v[3 * i + 2]};
+            float qq[4];
+            quat_exp<float>(vv, qq);
+            for (int k = 0; k < 4; ++k) q[4 * i + k] = qq[k];
+        } else {
+            const double vv[3] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+            double qq[4];
+            quat_exp<double>(vv, qq);
+            for (int k = 0; k < 4; ++k) q[4 * i + k] = qq[k];
+        }
+    }
+}
 // The quad arithmetic (ekf_quad.hpp) on an emulated quad; same contract as orc_run_batch.
 int64_t orc_quad_run_batch(const orc_params* p, int64_t B, int64_t T, double* x, double* P, const double* u, const double* z,
                            const uint8_t* mask, int dtype)

@@ -14,8 +14,9 @@ from bench import CFG3  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 65536
 step = int(sys.argv[2]) if len(sys.argv) > 2 else 12
+dtype = sys.argv[3] if len(sys.argv) > 3 else "f32"
 cfg = dict(CFG3, multirate_ekf=1, dynamic_meas_delay=1, measurement_delay=0.030, measurement_delay_max=0.200, dyn_measurement_delay_offset=0.005)
-ekf = qla.BatchedRelativePoseEKF(B, "f32", **cfg)
+ekf = qla.BatchedRelativePoseEKF(B, dtype, **cfg)
 T = 14 * 12
 thm = np.zeros(T, np.uint8); thm[13::14] = 1
 seq = ekf.make_inputs(T, thm)
@@ -29,7 +30,7 @@ L = C.CDLL(os.environ["QLE_LIB"])
 NS = 128
 nw = min(B // 64, 4096)
 buf = (C.c_ulonglong * (nw * NS))()
-rc = L.qle_debug_clocks_float(buf, nw * NS)
+rc = (L.qle_debug_clocks_float if dtype == "f32" else L.qle_debug_clocks_double)(buf, nw * NS)
 assert rc == 0, rc
 t = np.frombuffer(buf, dtype=np.uint64).reshape(nw, NS).astype(np.int64)
 t0 = t[:, 0]
@@ -50,4 +51,10 @@ for j in range(nj):
     a, b = np.median(rel(8 + 2 * j)), np.median(rel(9 + 2 * j))
     print(f"    iter {j:2d}: IMU sample in registers at {a:7.0f} (+{a - prev:6.0f} after the previous predict), predict done (x and P) at {b:7.0f} (predict {b - a:6.0f})")
     prev = b
+if dtype == "f64":   # phases of the last split predict (ekf_split.hpp)
+    sb = (C.c_ulonglong * (nw * 8))()
+    assert L.qle_debug_split_clocks_double(sb, nw * 8) == 0
+    st = np.frombuffer(sb, dtype=np.uint64).reshape(nw, 8).astype(np.int64)
+    d = np.diff(st[:, :4], axis=1)
+    print("  last split predict of a wave: row r %.0f, row v %.0f, rows th/ab/wb + noise %.0f cycles (medians)" % tuple(np.median(d, axis=0)))
 ekf.close()

@@ -146,17 +146,23 @@ struct Noise {
 };
 
 // sin(h) / (2 h) and cos(h): the vector scale and the scalar part of exp(phi), h = |phi| / 2 (QH.cpp:9-28).  Series in h^2 on
-// |h| <= pi/4 (truncation < 3e-10 in fp32, < 3e-20 in fp64); beyond, the library functions behind a branch no physical rate takes.
+// |h| <= pi/4 (truncation < 3e-10 in fp32, < 3e-20 in fp64).  Larger half-angles (no physical rate: more than 90 degrees per tick) are
+// halved until they fit and the result is doubled back -- sin 2a / 2a = (sin a / a) cos a, cos 2a = 1 - 2 a^2 (sin a / a)^2, no square
+// root.  The number of halvings is WAVE-UNIFORM (the largest any lane needs; normally zero, and then nothing below differs from the
+// plain series): a per-lane branch to the library's sincos here put a divergent region into the middle of kernels that sit at the
+// register limit, and the backend placed register copies at that region's join in front of the EXEC restore -- copies that never
+// happened for the lanes that had skipped the branch (profiles/r04_tuning.md section 1: the GPU memory access faults).
 template <typename T>
-__device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
+__host__ __device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
 {
-    if (__builtin_expect(h2 > T(0.6168502750680849), 0)) {   // (pi/4)^2
-        const T h = t_sqrt(h2);
-        T s;
-        t_sincos(h, &s, &ch);
-        k = T(0.5) * s / h;
-        return;
-    }
+    constexpr T kLim = T(0.6168502750680849);   // (pi/4)^2
+    int halvings = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    while (halvings < 600 && __any(h2 > kLim)) { h2 *= T(0.25); ++halvings; }
+#else
+    while (halvings < 600 && h2 > kLim) { h2 *= T(0.25); ++halvings; }
+#endif
+    T sc, cc;   // sin(a) / a and cos(a), a^2 = h2
     if (sizeof(T) == 4) {
         // sin h / h = 1 - h2/6 + h2^2/120 - h2^3/5040 + h2^4/362880 - h2^5/39916800
         T s = T(-2.505210838544172e-08);
@@ -165,14 +171,14 @@ __device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
         s = s * h2 + T(8.333333333333333e-03);
         s = s * h2 + T(-1.666666666666667e-01);
         s = s * h2 + T(1);
-        k = T(0.5) * s;
+        sc = s;
         T c = T(2.08767569878681e-09);
         c = c * h2 + T(-2.755731922398589e-07);
         c = c * h2 + T(2.48015873015873e-05);
         c = c * h2 + T(-1.388888888888889e-03);
         c = c * h2 + T(4.166666666666666e-02);
         c = c * h2 + T(-0.5);
-        ch = c * h2 + T(1);
+        cc = c * h2 + T(1);
     } else {
         // 1/(2n+1)! and 1/(2n)! down to n = 10
         T s = T(1.957294106339126e-20);
@@ -186,7 +192,7 @@ __device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
         s = s * h2 + T(8.333333333333333e-03);
         s = s * h2 + T(-1.666666666666667e-01);
         s = s * h2 + T(1);
-        k = T(0.5) * s;
+        sc = s;
         T c = T(4.110317623312165e-19);
         c = c * h2 + T(-1.561920696858623e-16);
         c = c * h2 + T(4.779477332387385e-14);
@@ -197,8 +203,16 @@ __device__ __forceinline__ void half_angle_sinc_cos(T h2, T& k, T& ch)
         c = c * h2 + T(-1.388888888888889e-03);
         c = c * h2 + T(4.166666666666666e-02);
         c = c * h2 + T(-0.5);
-        ch = c * h2 + T(1);
+        cc = c * h2 + T(1);
     }
+    for (int j = 0; j < halvings; ++j) {   // wave-uniform trip count
+        const T s2 = sc * sc * h2;
+        sc = sc * cc;
+        cc = T(1) - T(2) * s2;
+        h2 = h2 * T(4);
+    }
+    k = T(0.5) * sc;
+    ch = cc;
 }
 
 // ------------------------------------------------------ quaternion helpers

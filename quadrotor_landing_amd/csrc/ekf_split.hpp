@@ -29,10 +29,40 @@
 
 // Between two phases of the split algebra: nothing is scheduled across (the backend would otherwise hoist the next phase's LDS reads over
 // the current one and hold both block sets in registers).
+#ifndef QLE_FENCE_MASK
+#define QLE_FENCE_MASK 0   // sched_barrier mask: which instruction classes MAY still cross (0: none; 2 | 4: VALU and SALU)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
-#define QLE_PHASE_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define QLE_PHASE_FENCE() __builtin_amdgcn_sched_barrier(QLE_FENCE_MASK)
 #else
 #define QLE_PHASE_FENCE() do { } while (0)
+#endif
+
+// Diagnostic build only (make dbg): s_memtime at the phase boundaries of the LAST split predict a wave ran (lane 0 writes), read back
+// through qle_debug_split_clocks (tu_misc.hip).  Slots: 0 entry, 1 row r formed, 2 row v formed, 3 rows th / ab / wb done.
+#if defined(QLE_MR_STAMPS) && defined(__HIPCC__)
+namespace qle { static __device__ unsigned long long qle_dbg_split_clock[4096 * 8]; }
+#endif
+#if defined(QLE_MR_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define QLE_SPLIT_STAMP(k, dep)                                                                                             \
+    do {                                                                                                                    \
+        unsigned long long t_;                                                                                              \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) : "v"(dep) : "memory");                              \
+        const unsigned w_ = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;                                                   \
+        if ((threadIdx.x & 63) == 0 && w_ < 4096) ::qle::qle_dbg_split_clock[w_ * 8 + (k)] = t_;                            \
+    } while (0)
+#else
+#define QLE_SPLIT_STAMP(k, dep) do { } while (0)
+#endif
+
+// the fences inside the predict (the per-tick part of the replay loop) on their own switch: -DQLE_PREDICT_FENCES=0 leaves the backend free
+#ifndef QLE_PREDICT_FENCES
+#define QLE_PREDICT_FENCES 1
+#endif
+#if QLE_PREDICT_FENCES
+#define QLE_PREDICT_FENCE() QLE_PHASE_FENCE()
+#else
+#define QLE_PREDICT_FENCE() do { } while (0)
 #endif
 
 namespace qle {
@@ -134,6 +164,7 @@ __host__ __device__ __forceinline__ void split_predict_cov(const SplitCtx<T>& s,
     const T (&A)[9] = s.A;
     const T (&B)[9] = s.B;
     const T (&R)[9] = s.R;
+    QLE_SPLIT_STAMP(0, lo[0] + A[0]);
     // ---- block-row r ------------------------------------------------------------------------------------------------------------
     {
         T Mw[9], Ma[9], Mt[9], Mv[9], rvo[9], rr[6];
@@ -181,7 +212,8 @@ __host__ __device__ __forceinline__ void split_predict_cov(const SplitCtx<T>& s,
 #pragma unroll
         for (int k = 0; k < 9; ++k) top.st(T_RW + k, Mw[k]);
     }
-    QLE_PHASE_FENCE();
+    QLE_SPLIT_STAMP(1, lo[0]);
+    QLE_PREDICT_FENCE();
     // ---- block-row v ------------------------------------------------------------------------------------------------------------
     {
         T Mw[9], Ma[9], Mt[9], vto[9], vao[9];
@@ -241,7 +273,8 @@ __host__ __device__ __forceinline__ void split_predict_cov(const SplitCtx<T>& s,
 #pragma unroll
         for (int k = 0; k < 9; ++k) top.st(T_VW + k, Mw[k]);
     }
-    QLE_PHASE_FENCE();
+    QLE_SPLIT_STAMP(2, lo[0]);
+    QLE_PREDICT_FENCE();
     // ---- block-row th (registers) -----------------------------------------------------------------------------------------------
     {
         T N[9], tw[9], ta[9];
@@ -271,6 +304,7 @@ __host__ __device__ __forceinline__ void split_predict_cov(const SplitCtx<T>& s,
         lo[L_AA + sym3(i, i)] += nz.Q[6 + i];
         lo[L_WW + sym3(i, i)] += nz.Q[9 + i];
     }
+    QLE_SPLIT_STAMP(3, lo[L_TT] + lo[L_WW]);
 }
 
 // prediction_step, EKF.cpp:346-415, on the split covariance.

@@ -13,6 +13,10 @@ extern "C" int QLE_CAT(qle_debug_clocks_, QLE_TU_T)(unsigned long long* out, int
 {
     return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qle::qle_dbg_clock), sizeof(unsigned long long) * (size_t)n);
 }
+extern "C" int QLE_CAT(qle_debug_split_clocks_, QLE_TU_T)(unsigned long long* out, int n)
+{
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(qle::qle_dbg_split_clock), sizeof(unsigned long long) * (size_t)n);
+}
 #endif
 
 // One multirate tick that carries tag poses (predict-only multirate ticks go through launch_predict).
@@ -42,8 +46,30 @@ int launch_step_mr(qle_batch* h, const void* u, const void* z)
         QLE_MR_LAUNCH1(D, F);                                                                                                          \
     } while (0)
 #define QLE_MR_LAUNCH1(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, lds, h->stream, p, gp, m, (T*)state_cur(h), (T*)h->mr_u, (T*)h->mr_ckpt, (T*)h->mr_anchor, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
+#ifdef QLE_DEBUG_PTRS   // diagnostic builds only: where every buffer of the launch lies (to place a fault address)
+    {
+        const size_t sb = slot_bytes(h);
+        std::fprintf(stderr, "[qle] k_step_mr tick %lld B %lld block %d lds %zu e_tick %lld\n", (long long)h->tick, (long long)h->B, h->block, lds, (long long)h->e_tick);
+        auto rng = [](const char* n, const void* p0, size_t bytes) { std::fprintf(stderr, "[qle]   %-10s %p .. %p (%zu B)\n", n, p0, (const char*)p0 + bytes, bytes); };
+        rng("cur", state_cur(h), sb);
+        rng("mr_u", h->mr_u, (size_t)h->mr_Cu * kHW * (size_t)h->Bp * h->wsz);
+        rng("mr_ckpt", h->mr_ckpt, (size_t)(h->mr_Nc + 1) * sb);
+        rng("mr_anchor", h->mr_anchor, sb);
+        rng("u", u, (size_t)kUW * h->Bp * h->wsz);
+        rng("z", z, (size_t)kZW * h->Bp * h->wsz);
+        rng("hist_first", h->hist_first, 4 * (size_t)h->Bp);
+        rng("last_corr", h->last_corr, h->last_corr ? 4 * (size_t)h->Bp : 0);
+        rng("flags", h->flags, h->flags ? (size_t)h->Bp : 0);
+        rng("delay_cur", h->delay_cur, 8 * (size_t)h->Bp);
+        rng("stamp", h->stamp, 8 * (size_t)h->Bp);
+        std::fflush(stderr);
+    }
+#endif
     if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_MR_LAUNCH(true, true); else QLE_MR_LAUNCH(true, false); }
     else { if (h->pfp_on) QLE_MR_LAUNCH(false, true); else QLE_MR_LAUNCH(false, false); }
+#ifdef QLE_DEBUG_PTRS
+    { hipError_t e_ = hipStreamSynchronize(h->stream); std::fprintf(stderr, "[qle]   launch done: %s\n", hipGetErrorString(e_)); }
+#endif
 #undef QLE_MR_LAUNCH
 #undef QLE_MR_LAUNCH1
     HIP_TRY(hipGetLastError());

@@ -33,8 +33,10 @@ static int launch_quad_dg(qle_batch* h, const void* u, const void* z)
 #define QLE_QT_LAUNCH_W(F, N, W) hipLaunchKernelGGL((kw_tick<T, DIRECT, F, GATE, STEP, N, W>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split)
 #define QLE_QT_LAUNCH(F, N) do { if (fpw == 16) QLE_QT_LAUNCH_W(F, N, 16); else QLE_QT_LAUNCH_W(F, N, 64); } while (0)
 #define QLE_QT_N(N) do { if (h->pfp_on) QLE_QT_LAUNCH(true, N); else QLE_QT_LAUNCH(false, N); } while (0)
+    // the "split" policy (3) belongs to states larger than the Infinity Cache, where this kernel is never selected (<= 4 096 filters);
+    // under a QLE_NT=3 override it runs with cached accesses
     const int nt = effective_nt(h);
-    if (nt == 3) QLE_QT_N(3); else if (nt == 2) QLE_QT_N(2); else if (nt == 1) QLE_QT_N(1); else QLE_QT_N(0);
+    if (nt == 2) QLE_QT_N(2); else if (nt == 1) QLE_QT_N(1); else QLE_QT_N(0);
 #undef QLE_QT_N
 #undef QLE_QT_LAUNCH
 #undef QLE_QT_LAUNCH_W

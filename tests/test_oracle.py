@@ -414,6 +414,28 @@ def engine_cpu_run(variant, p, x, P, U, Z, M, dtype):
     return oracle.structured_run_batch(p, x, P, U, Z, M, dtype=dtype, levels=variant if variant in ("fused", "packed", "split") else (variant == "levels"))
 
 
+def test_engine_quaternion_exp_large_angles_halving_and_doubling():
+    """quaternion_exp of the engine (ekf_device.hpp, host build): the half-angle series on |phi|/2 <= pi/4 and, beyond, halving until the
+    series applies and doubling back (a wave-uniform count on the device; no branch to the library's sincos).  Against the closed form
+    (QH.cpp:9-33 incl. the final quaternion_norm) for rotation vectors from 1e-12 rad to 40 rad."""
+    rng = np.random.default_rng(7)
+    n = 4000
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = np.concatenate([10 ** rng.uniform(-12, 0.15, n // 2), rng.uniform(1.4, 40.0, n - n // 2)])
+    v = ax * ang[:, None]
+    for dtype, tol in (("f64", 2e-14), ("f32", 5e-6)):   # fp32: |v|^2 carries 1e-7 relative, i.e. 1.5e-6 rad at 30 rad, before any series
+        vr = v.astype(np.float32).astype(np.float64) if dtype == "f32" else v     # the closed form on the inputs the engine sees
+        a = np.linalg.norm(vr, axis=1)
+        ref = np.concatenate([vr / a[:, None] * np.sin(a / 2)[:, None], np.cos(a / 2)[:, None]], axis=1)
+        ref[ref[:, 3] < -0.75] *= -1                   # quaternion_norm's flip, QH.cpp:61-73
+        q = oracle.structured_quat_exp(v, dtype)
+        err = np.abs(q - ref).max(axis=1)
+        small = ang < 1.5
+        assert err[small].max() < (4e-16 if dtype == "f64" else 2e-7), (dtype, err[small].max())
+        assert err.max() < tol, (dtype, err.max(), ang[err.argmax()])
+        assert np.abs(np.linalg.norm(q, axis=1) - 1).max() < (1e-15 if dtype == "f64" else 3e-7)
+
+
 def test_packed_covariance_order_is_a_bijection_with_level_structure():
     """sidx (ekf_device.hpp) restated: 120 distinct words, block-rows in storage order r, v, th, ab, wb quad-wise,
     memory quad 3m + l = the m-th quad of quad-lane l, and lane l holds column l of every off-diagonal block."""
