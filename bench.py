@@ -50,7 +50,13 @@ WORKLOADS = {
     "cfg5": "cfg5: Monte-Carlo sweep, 262144 filters in all sharded over the ranks, per-filter Q scaled by 10^U(-0.5,0.5) and static biases, "
             "400 Hz predict + 30 Hz update, per-device RMSE reduction",
     "cfg3mr": "cfg3 with multirate_ekf: 30 Hz tag poses arrive 12 ticks late, corrected in the history ring and replayed",
+    # the two parameter files the reference ships (quad_state_estimation/config), as filter_update runs them in the field
+    "rotors": "relative_pose_EKF_rotors.yaml as shipped: 100 Hz IMU, 15 Hz tag poses (every 7th tick, rate limit on), multirate EKF with dynamic "
+              "delay (3-tick camera latency), 1-tag corner gate, decisions on the device",
+    "hardware": "relative_pose_EKF_hardware.yaml as shipped: 100 Hz IMU, 100 Hz tag poses (a correction + 15-tick replay on EVERY tick), multirate EKF "
+                "with dynamic delay, 13-tag corner gate, static IMU biases, decisions on the device",
 }
+YAML = {"rotors": "ekf_sim_rotors.yaml", "hardware": "ekf_hardware.yaml"}
 
 
 def cpu_share():
@@ -255,6 +261,18 @@ def main():
         perturb = True
         global_default = 262144
     mr_step = 0
+    params = None
+    if args.workload in YAML:
+        # everything from the shipped file (relative_pose_EKF_{rotors,hardware}.yaml re-laid-out under quadrotor_landing_amd/config):
+        # cadence, delays, noise, static biases, camera and tag bundle, flags
+        from quadrotor_landing_amd import params as qparams
+        params = qparams.load_yaml(os.path.join(ROOT, "quadrotor_landing_amd", "config", YAML[args.workload]))
+        der = qparams.derive(params)
+        cfg = {}
+        upd = int(der.upd_per_meas)                                   # ceil(update_freq / measurement_freq), EKF.cpp:91
+        mr_step = int(der.measurement_step_delay)                     # int(measurement_delay / dT + 0.5), EKF.cpp:93
+        if args.steps == 4000:
+            args.steps, args.warmup = 1400, 70
     if args.workload == "cfg3mr":
         # delays of relative_pose_EKF_rotors.yaml:5-7 at 400 Hz: step delay int(0.030/0.0025 + 0.5) = 12 ticks
         cfg.update(multirate_ekf=1, dynamic_meas_delay=1, measurement_delay=0.030, measurement_delay_max=0.200,
@@ -303,12 +321,15 @@ def main():
     T = max(upd, (T // upd) * upd)  # whole measurement periods so the wrapped schedule stays periodic
     thm = np.zeros(T, np.uint8); thm[upd - 1::upd] = 1
 
-    ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, **cfg)
+    ekf = qla.BatchedRelativePoseEKF(B, args.dtype, device=device, params=params, **cfg)
+    if params is not None:
+        ekf.enable_gating(True)   # rate limit + corner gate per filter on the device (EKF.cpp:147-186), as the node runs them
     pol = ekf.policy()
     seq = ekf.make_inputs(T, thm)
-    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg4": 0xE4F00003, "cfg5": 0xE4F00005, "cfg3mr": 0xE4F00003}[args.workload]
+    seed = {"cfg2": 0xE4F00002, "cfg3": 0xE4F00003, "cfg4": 0xE4F00003, "cfg5": 0xE4F00005, "cfg3mr": 0xE4F00003,
+            "rotors": 0xE4F00006, "hardware": 0xE4F00007}[args.workload]
     if mr_step:
-        ekf.set_uniform_measurement_age(mr_step / cfg["update_freq"] - cfg["dyn_measurement_delay_offset"])
+        ekf.set_uniform_measurement_age(mr_step / ekf.params.update_freq - ekf.params.dyn_measurement_delay_offset)
     ekf.synth_generate(seq, seed=seed, filter_offset=offset, perturb_filter_params=perturb, meas_delay_ticks=mr_step)
     x0 = P0 = None
     if rank == 0 and not args.no_cpu_baseline and world == 1 and args.workload == "cfg3":
@@ -366,9 +387,16 @@ def main():
         # starts from (136: the extra checkpoint a predict tick wrote at the expected entry of this tag pose, so nothing is replayed in
         # front of the correction) + the stored IMU samples of the replayed ticks (8 words each); write the anchor (136), the state
         # (136), its IMU sample (8), the grid checkpoints passed on the way (136 x step / k, k = 32) -- and that extra checkpoint (136)
-        words = (6 + 8 + 136 + 8 * mr_step) + (136 + 136 + 8 + 136 * mr_step // 32) + 136
+        # (a correction on every tick, upd == 1: the chain starts one tick before the entry, from the anchor, and no extra checkpoint exists)
+        words = (6 + 8 + 136 + 8 * (mr_step + (upd == 1))) + (136 + 136 + 8 + 136 * mr_step // 32) + (136 if upd > 1 else 0)
         bytes_mixed = (K - n_upd) * ekf.algorithmic_bytes(0) + n_upd * words * wsz * B
     bad = ekf.count_nonfinite()
+    decisions = None
+    if params is not None:   # what the device-side decisions (EKF.cpp:147-186) did on the last timed tick that carried tag poses
+        pc, co, up = ekf.tick_flags()
+        decisions = {"performed_correction_frac": float(pc.mean()), "measurement_consumed_frac": float(co.mean()),
+                     "upds_since_correction_max": int(up.max()), "upd_per_meas": upd, "measurement_step_delay": mr_step,
+                     "n_tags": int(ekf.params.n_tags)}
     # per-device error sums vs the generator's truth (cfg 5 reduction).  The truth is the pose after ONE pass over the resident
     # sequence and the trajectory is not periodic in T, so the timed regions (which wrap `wraps_in_timed_regions` times) say nothing
     # about tracking: the filters are re-seeded and run through exactly one untimed pass 0..T first.
@@ -458,6 +486,8 @@ def main():
         "nonfinite_filters": bad,
         "head": head_sha(),
     }
+    if decisions is not None:
+        out["device_decisions"] = decisions
     if rm is not None:
         from quadrotor_landing_amd.sharding import combine_rmse
         r_r, r_th, n = combine_rmse([rm])

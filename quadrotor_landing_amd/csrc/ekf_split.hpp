@@ -55,9 +55,11 @@ namespace qle { static __device__ unsigned long long qle_dbg_split_clock[4096 * 
 #define QLE_SPLIT_STAMP(k, dep) do { } while (0)
 #endif
 
-// the fences inside the predict (the per-tick part of the replay loop) on their own switch: -DQLE_PREDICT_FENCES=0 leaves the backend free
+// The fences inside the predict (the per-tick part of the replay loop) have their own switch.  They are OFF: with MachineLICM off for the
+// unit (Makefile) the predict needs none to stay out of scratch, and without them the backend overlaps the nominal-state chain with
+// the LDS round trips of block-row r (k_step_mr<double> 94.0 -> 89.6 us, profiles/r04_tuning.md section 2).  The correction keeps its fences.
 #ifndef QLE_PREDICT_FENCES
-#define QLE_PREDICT_FENCES 1
+#define QLE_PREDICT_FENCES 0
 #endif
 #if QLE_PREDICT_FENCES
 #define QLE_PREDICT_FENCE() QLE_PHASE_FENCE()

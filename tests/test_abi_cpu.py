@@ -4,6 +4,8 @@ oracle, and the engine fails loudly without a GPU (no CPU fallback)."""
 import ctypes as C
 import os
 import re
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -162,3 +164,33 @@ def test_cpp_driver_parses_config_and_fails_loudly_without_gpu():
     assert r.returncode == 1 and "no CPU fallback" in r.stderr
     r = subprocess.run([exe, "--config", "/nonexistent.yaml"], capture_output=True, text=True)
     assert r.returncode == 2
+
+
+def test_generated_device_code_passes_the_stale_exec_audit(tmp_path):
+    """The backend must not place register copies at a control-flow join in front of the EXEC restore (the cause of the GPU memory access
+    faults of rounds 3 and 4, profiles/r04_tuning.md section 1).  `make audit` compiles every translation unit to device assembly with the
+    flags the library is built with (cached under csrc/build/asm) and runs profiles/r04_scripts/exec_join_audit.py over it; the script itself is
+    checked here on a reduced copy of the faulting pattern and of its repaired form."""
+    audit = os.path.join(ROOT, "profiles", "r04_scripts", "exec_join_audit.py")
+    bad = tmp_path / "bad.s"
+    bad.write_text("""_Z6kernelv:
+\ts_and_saveexec_b64 s[0:1], vcc
+\ts_cbranch_execz .LBB0_2
+\tv_add_f64 v[2:3], v[2:3], v[4:5]
+.LBB0_2:
+\tv_accvgpr_write_b32 a4, v252
+\tv_accvgpr_write_b32 a5, v253
+\ts_or_b64 exec, exec, s[0:1]
+\tv_accvgpr_read_b32 v252, a4
+\ts_endpgm
+""")
+    good = tmp_path / "good.s"
+    good.write_text(bad.read_text().replace("\tv_accvgpr_write_b32 a4, v252\n\tv_accvgpr_write_b32 a5, v253\n\ts_or_b64 exec, exec, s[0:1]\n",
+                                            "\ts_or_b64 exec, exec, s[0:1]\n\tv_accvgpr_write_b32 a4, v252\n\tv_accvgpr_write_b32 a5, v253\n"))
+    rb = subprocess.run([sys.executable, audit, str(bad)], capture_output=True, text=True)
+    rg = subprocess.run([sys.executable, audit, str(good)], capture_output=True, text=True)
+    assert rb.returncode == 1 and "2 register copies under a stale EXEC" in rb.stdout, rb.stdout
+    assert rg.returncode == 0 and rg.stdout.strip() == "", rg.stdout
+    r = subprocess.run(["make", "-C", os.path.join(ROOT, "quadrotor_landing_amd", "csrc"), "audit"], capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "audit: no register copy under a stale EXEC in 11 translation units" in r.stdout

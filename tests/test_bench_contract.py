@@ -30,7 +30,8 @@ def test_cpu_share_and_argument_defaults():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("extra", [[], ["--workload", "cfg5"], ["--workload", "cfg3mr"], ["--workload", "cfg2"]])
+@pytest.mark.parametrize("extra", [[], ["--workload", "cfg5"], ["--workload", "cfg3mr"], ["--workload", "cfg2"], ["--workload", "rotors"],
+                                   ["--workload", "hardware"], ["--workload", "hardware", "--dtype", "f64"]])
 def test_bench_json_contract(extra):
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "42", "--warmup", "14", "--batch-per-gpu", "4096",
            "--predict-only-steps", "60"] + extra
@@ -56,8 +57,15 @@ def test_bench_json_contract(extra):
     assert rf["served_by"] in ("infinity_cache", "hbm", "split") and abs(rf["frac_of_measured_copy"] - rf["achieved"] / 6290.0) < 1e-12
     # 4 096 filters: the workgroup-cooperative kernel takes every single-rate tick at this size (quarter-tile workgroups)
     want_kernel = {"": "kw_tick<float,predict>", "cfg5": "kw_tick<float,predict>", "cfg3mr": "k_predict<float,MR>",
-                   "cfg2": "kw_tick<double,step>"}[extra[1] if extra else ""]
+                   "cfg2": "kw_tick<double,step>", "rotors": "k_predict<float,MR>", "hardware": "k_step_mr<float>"}[extra[1] if extra else ""]
+    if "f64" in extra:
+        want_kernel = want_kernel.replace("float", "double")
     assert rf["kernel"] == want_kernel, rf["kernel"]
+    if extra and extra[1] in ("rotors", "hardware"):   # the shipped parameter files: decisions on the device, every synthetic pose in view
+        dd = d["device_decisions"]
+        assert dd["upd_per_meas"] == (7 if extra[1] == "rotors" else 1) and dd["measurement_step_delay"] == (3 if extra[1] == "rotors" else 15)
+        assert dd["n_tags"] == (1 if extra[1] == "rotors" else 13)
+        assert dd["measurement_consumed_frac"] == 1.0 and dd["performed_correction_frac"] > 0.9
     assert sum(rf["mixed_kernels"].values()) == 42
     if not extra:
         for sub in ("hbm_resident", "f64_same_batch"):
@@ -73,7 +81,7 @@ def test_bench_json_contract(extra):
         cb = d["cpu_baseline"]
         assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
         assert d["dtype"] == "f32"
-    if extra == ["--workload", "cfg2"]:
+    if extra == ["--workload", "cfg2"] or "f64" in extra:
         assert d["dtype"] == "f64"
 
 
