@@ -238,6 +238,10 @@ typedef struct qle_synth_cfg {
     int32_t perturb_filter_params;       /* cfg 5: also fill per-filter Q scale and static biases */
     int32_t meas_delay_ticks;            /* multirate runs: a tag pose delivered at tick t shows the pose after tick
                                             t - meas_delay_ticks (0 = no latency, single-rate) */
+    double view_scale;                   /* 1 = the free flight of the BASELINE configs; < 1 shrinks the lateral offsets and
+                                            amplitudes of the trajectory and its attitude excursions by this factor, so that the
+                                            tag bundle stays inside the image -- a landing approach, what the node sees while it
+                                            has detections at all (the corner gate of EKF.cpp:147-186 then passes) */
 } qle_synth_cfg;
 int qle_synth_cfg_default(qle_synth_cfg *c);
 /* Fill `in` with a generated sequence and seed the filters from the first

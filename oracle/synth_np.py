@@ -98,7 +98,7 @@ def _measure(cfg, gi, tick, r, q, R):
 
 
 def generate(p, B, tick_has_meas, seed, filter_offset=0, perturb_filter_params=False, ab_true_sigma=0.1, wb_true_sigma=0.01,
-             meas_noise_scale=1.0, imu_noise_scale=1.0, meas_delay_ticks=0):
+             meas_noise_scale=1.0, imu_noise_scale=1.0, meas_delay_ticks=0, view_scale=1.0):
     """What qle_synth_generate leaves on the device, for the orc_params `p` (oracle.make_params): a dict with
     u [T, B, 6], z [slots, B, 7] (one entry per tick whose tick_has_meas is set, in order), z0 [B, 7] (seeding tag pose),
     pfp [B, 24] (per-filter Q, static biases, R) or None, truth [B, 7], truth_bias [B, 6]."""
@@ -116,11 +116,12 @@ def generate(p, B, tick_has_meas, seed, filter_offset=0, perturb_filter_params=F
     def Nrm(ch):
         return rng_normal(seed, gi, TICK_STATIC, 100 + ch)
 
-    r0 = np.stack([U(0, -1, 1), U(1, -1, 1), U(2, 1, 4)], axis=1)
-    A = np.stack([U(3 + k, 0, 0.5) for k in range(3)], axis=1)
+    vs = float(view_scale) if 0.0 < view_scale <= 1.0 else 1.0   # < 1: lateral offsets / amplitudes and attitude excursions shrunk
+    r0 = np.stack([vs * U(0, -1, 1), vs * U(1, -1, 1), U(2, 1, 4)], axis=1)
+    A = np.stack([(vs if k < 2 else 1.0) * U(3 + k, 0, 0.5) for k in range(3)], axis=1)
     om = np.stack([U(6 + k, 0.2, 1.5) for k in range(3)], axis=1)
     ph = np.stack([U(9 + k, 0, 6.283185307179586) for k in range(3)], axis=1)
-    wa = np.stack([U(12 + k, 0, 0.3) for k in range(3)], axis=1)
+    wa = np.stack([vs * U(12 + k, 0, 0.3) for k in range(3)], axis=1)
     wo = np.stack([U(15 + k, 0.2, 1.5) for k in range(3)], axis=1)
     wp = np.stack([U(18 + k, 0, 6.283185307179586) for k in range(3)], axis=1)
     if p.est_bias:
@@ -128,7 +129,7 @@ def generate(p, B, tick_has_meas, seed, filter_offset=0, perturb_filter_params=F
         wb = np.stack([wb_true_sigma * Nrm(3 + k) for k in range(3)], axis=1)
     else:
         ab = np.zeros((B, 3)); wb = np.zeros((B, 3))
-    q = _qexp(np.stack([0.2 * Nrm(6), 0.2 * Nrm(7), 0.2 * Nrm(8)], axis=1))
+    q = _qexp(np.stack([vs * 0.2 * Nrm(6), vs * 0.2 * Nrm(7), vs * 0.2 * Nrm(8)], axis=1))
 
     # per-filter filter parameters (BASELINE cfg 5): Q groups scaled by 10^U(-0.5, 0.5), static biases ~ N(0, 0.1^2), N(0, 0.01^2)
     Qf = np.tile(Q, (B, 1)); abs_ = np.tile(np.array(p.ab_static[:3]), (B, 1)); wbs_ = np.tile(np.array(p.wb_static[:3]), (B, 1))

@@ -51,7 +51,7 @@ class QleSynthCfg(C.Structure):
     _fields_ = [
         ("seed", _u64), ("filter_offset", _i64),
         ("ab_true_sigma", _d), ("wb_true_sigma", _d), ("meas_noise_scale", _d), ("imu_noise_scale", _d),
-        ("perturb_filter_params", _i32), ("meas_delay_ticks", _i32),
+        ("perturb_filter_params", _i32), ("meas_delay_ticks", _i32), ("view_scale", _d),
     ]
 
 

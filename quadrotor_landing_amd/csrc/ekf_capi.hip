@@ -960,6 +960,7 @@ extern "C" int qle_synth_cfg_default(qle_synth_cfg* c)
     c->wb_true_sigma = 0.01;
     c->meas_noise_scale = 1.0;
     c->imu_noise_scale = 1.0;
+    c->view_scale = 1.0;
     return QLE_OK;
 }
 
@@ -973,6 +974,7 @@ static int synth_t(qle_batch* h, qle_inputs* in, const qle_synth_cfg* c)
     a.wb_sigma = c->wb_true_sigma;
     a.meas_scale = c->meas_noise_scale;
     a.imu_scale = c->imu_noise_scale;
+    a.view_scale = (c->view_scale > 0.0 && c->view_scale <= 1.0) ? c->view_scale : 1.0;
     a.perturb = c->perturb_filter_params;
     a.meas_delay_ticks = c->meas_delay_ticks < 0 ? 0 : (c->meas_delay_ticks > kSynthMaxDelay ? kSynthMaxDelay : c->meas_delay_ticks);
     a.dT = h->der.dT_nom;

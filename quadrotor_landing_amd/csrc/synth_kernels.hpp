@@ -21,7 +21,7 @@ struct SynthArgs {
     double ab_sigma, wb_sigma, meas_scale, imu_scale;
     int32_t perturb, est_bias;
     int32_t meas_delay_ticks, _pad;   // tag pose delivered at tick t was taken meas_delay_ticks-1 ticks earlier (multirate runs)
-    double dT;
+    double dT, view_scale;
     double Q[12], R[6], g[3], r_v_cv[3], q_vc[4], C_vc[9], ab_static[3], wb_static[3];
     int64_t T, B, pitch_u_words, pitch_z_words;
 };
@@ -64,18 +64,19 @@ __device__ inline void synth_static(const SynthArgs& a, uint64_t gi, SynthTruth&
 {
     auto U = [&](uint64_t ch, double lo, double hi) { return lo + (hi - lo) * rng_uniform(a.seed, gi, kTickStatic, ch); };
     auto Nrm = [&](uint64_t ch) { return rng_normal(a.seed, gi, kTickStatic, 100 + ch); };
-    s.r0[0] = U(0, -1, 1); s.r0[1] = U(1, -1, 1); s.r0[2] = U(2, 1, 4);
+    const double vs = a.view_scale;   // < 1: lateral offsets / amplitudes and attitude excursions shrunk (the tag stays in the image)
+    s.r0[0] = vs * U(0, -1, 1); s.r0[1] = vs * U(1, -1, 1); s.r0[2] = U(2, 1, 4);
     for (int k = 0; k < 3; ++k) {
-        s.A[k] = U(3 + k, 0, 0.5);
+        s.A[k] = (k < 2 ? vs : 1.0) * U(3 + k, 0, 0.5);
         s.om[k] = U(6 + k, 0.2, 1.5);
         s.ph[k] = U(9 + k, 0, 6.283185307179586);
-        s.wa[k] = U(12 + k, 0, 0.3);
+        s.wa[k] = vs * U(12 + k, 0, 0.3);
         s.wo[k] = U(15 + k, 0.2, 1.5);
         s.wp[k] = U(18 + k, 0, 6.283185307179586);
         s.ab[k] = a.est_bias ? a.ab_sigma * Nrm(k) : 0.0;
         s.wb[k] = a.est_bias ? a.wb_sigma * Nrm(3 + k) : 0.0;
     }
-    double v[3] = {0.2 * Nrm(6), 0.2 * Nrm(7), 0.2 * Nrm(8)};
+    double v[3] = {vs * 0.2 * Nrm(6), vs * 0.2 * Nrm(7), vs * 0.2 * Nrm(8)};
     quat_exp<double>(v, s.q);
 }
 

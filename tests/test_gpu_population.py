@@ -204,7 +204,8 @@ def test_filters_initialise_on_their_own_first_detection(dtype, multirate, kerne
 
 
 @pytest.mark.parametrize("case", [dict(dtype="f64", perturb=False, delay=0, est_bias=1), dict(dtype="f64", perturb=True, delay=7, est_bias=1),
-                                  dict(dtype="f32", perturb=True, delay=0, est_bias=1), dict(dtype="f64", perturb=False, delay=3, est_bias=0)])
+                                  dict(dtype="f32", perturb=True, delay=0, est_bias=1), dict(dtype="f64", perturb=False, delay=3, est_bias=0),
+                                  dict(dtype="f64", perturb=False, delay=15, est_bias=1, view=0.2)])
 def test_device_generator_against_host_restatement(case, kernel_family):
     """The synthetic source that replaces the node's two ROS topics (k_synth, synth_kernels.hpp) against its numpy
     restatement (oracle/synth_np.py): every IMU record, every tag pose (incl. the delayed ones of multirate runs), the
@@ -221,9 +222,12 @@ def test_device_generator_against_host_restatement(case, kernel_family):
     thm = np.zeros(T, np.uint8); thm[4::7] = 1; thm[0] = 1
     ekf = qla.BatchedRelativePoseEKF(B, case["dtype"], **kw)
     seq = ekf.make_inputs(T, thm)
-    ekf.synth_generate(seq, seed=0xC0FFEE123, filter_offset=off, perturb_filter_params=case["perturb"], meas_delay_ticks=case["delay"])
+    view = case.get("view", 1.0)     # < 1: the landing approach of the shipped-file workloads (bench.py --workload rotors | hardware)
+    ekf.synth_generate(seq, seed=0xC0FFEE123, filter_offset=off, perturb_filter_params=case["perturb"], meas_delay_ticks=case["delay"], view_scale=view)
     ref = synth_np.generate(oracle.make_params(**kw), B, thm, seed=0xC0FFEE123, filter_offset=off, perturb_filter_params=case["perturb"],
-                            meas_delay_ticks=case["delay"])
+                            meas_delay_ticks=case["delay"], view_scale=view)
+    if view < 1.0:
+        assert np.abs(ref["truth"][:, :2]).max() < 1.5 * view + 1e-9   # lateral offset + amplitude, both shrunk
     f32 = case["dtype"] == "f32"
     rt = 3e-7 if f32 else 1e-12
 
