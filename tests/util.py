@@ -2,6 +2,7 @@
 import json
 import math
 import os
+import re
 
 import numpy as np
 
@@ -112,12 +113,27 @@ def quat_err(a, b):
 # to the tolerance it was held against, per test, so that the stated tolerances can be audited (and re-derived) from a GPU run:
 # tests/tolerances.md is that table.  A tolerance more than ~10x its measured deviation hides regressions.
 _REC = []
+_TIGHT = {}
+_tight_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tolerances_tight.json")
+if os.path.exists(_tight_path) and not os.environ.get("QLE_TOL_STATED"):   # QLE_TOL_STATED=1: the stated tolerances only (to re-derive the table)
+    _TIGHT = json.load(open(_tight_path))
+
+
+def _test_key():
+    t = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0]
+    t = t.split("::", 1)[1] if "::" in t else t
+    return re.sub(r"\[(default|lanes-only|coop-forced)-?", "[", t).replace("[]", "")
 
 
 def note(kind, value, tol):
+    """Every engine-vs-reference comparison passes through here.  The deviation is held against the smaller of the tolerance the test
+    states and the entry of tests/tolerances_tight.json (50 x the deviation an MI355X run measured, for comparisons whose stated
+    tolerance was more than 100 x that measurement: tests/make_tolerances.py), and recorded when QLE_TOL_RECORD is set."""
     value = float(value)
+    eff = min(float(tol), _TIGHT.get(f"{_test_key()}|{kind}|{float(tol):.3e}", float(tol)))
     if os.environ.get("QLE_TOL_RECORD"):
-        _REC.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], kind, value, float(tol)))
+        _REC.append((os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0], kind, value, eff, float(tol)))
+    assert value <= eff or not (value == value), f"{kind}: deviation {value:.3e} above the tolerance in force {eff:.3e} (stated {float(tol):.3e})"
     return value
 
 
@@ -125,12 +141,12 @@ def _dump_rec():
     path = os.environ.get("QLE_TOL_RECORD")
     if path and _REC:
         agg = {}
-        for test, kind, v, tol in _REC:
-            k = (test, kind, tol)
+        for test, kind, v, tol, stated in _REC:
+            k = (test, kind, tol, stated)
             agg[k] = max(agg.get(k, 0.0), v)
         with open(path, "a") as fh:
-            for (test, kind, tol), v in sorted(agg.items()):
-                fh.write(json.dumps(dict(test=test, kind=kind, measured=v, tol=tol)) + "\n")
+            for (test, kind, tol, stated), v in sorted(agg.items()):
+                fh.write(json.dumps(dict(test=test, kind=kind, measured=v, tol=tol, stated=stated)) + "\n")
 
 
 import atexit  # noqa: E402
