@@ -62,14 +62,42 @@ __host__ __device__ constexpr int block_row_last_word(int b)
     return r;
 }
 
+// Gx = Cc [Cc^T r]x of the conventional orientation method (EKF.cpp:455-458; the expressions of quad::update_noise).
+template <typename T>
+__host__ __device__ __forceinline__ void conventional_gx(const T (&x)[16], T (&Gx)[9])
+{
+    const T q[4] = {x[6], x[7], x[8], x[9]};
+    T Cc[9], b[3];
+    quat_to_rot(q, Cc);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) b[i] = Cc[i] * x[0] + Cc[3 + i] * x[1] + Cc[6 + i] * x[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const T c0 = Cc[3 * i], c1 = Cc[3 * i + 1], c2 = Cc[3 * i + 2];
+        Gx[3 * i] = c1 * b[2] - c2 * b[1];
+        Gx[3 * i + 1] = c2 * b[0] - c0 * b[2];
+        Gx[3 * i + 2] = c0 * b[1] - c1 * b[0];
+    }
+}
+
 // x: state at tick n-1 in, state at tick n out.  Po: covariance at tick n-1.  `corr`: this lane fuses the tag pose z; `live`: the
 // filter is initialised (a lane that is not stores nothing: corr implies live).
 // emit_accel(accel) / emit_obs(obs): side outputs as soon as they exist.  store_quad(q4 as a std::integral_constant, ptr to 4 final words): 4-word group q4 of
 // the new covariance is final (called for q4 = 29 .. 0 on every lane); store_x(): x is final.
-template <typename T, bool DIRECT, typename EmitAccel, typename EmitObs, typename StoreX, typename StoreQuad>
-__device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Noise<T>& nzl, T (&x)[16], const T (&Po)[120], const T (&u)[6],
-                                               const T (&z)[7], bool corr, bool live, EmitAccel&& emit_accel, EmitObs&& emit_obs,
-                                               StoreX&& store_x, StoreQuad&& store_quad)
+// tag_pose(zz): the tag pose z of this lane, asked for AFTER the covariance sweep, where the innovation needs it -- a caller may read it
+// from memory again there (fp64: 14 registers that do not have to stay live through the sweep) or hand over what it loaded at the start.
+// park(x) / unpark(x): called right before and right after the covariance sweep of a correcting lane; parked = whether park moved
+// the nominal state out of the registers (fp64: into the LDS) for the duration of the sweep.  The sweep itself needs r and q only, and
+// only in the conventional method (Gx per block-row): unpark(xl) before each of those evaluations then reads them back into a copy.
+struct FusedNoPark {
+    static constexpr bool parked = false;
+    template <typename X> __host__ __device__ __forceinline__ void operator()(X&) const {}
+};
+template <typename T, bool DIRECT, typename TagPose, typename EmitAccel, typename EmitObs, typename StoreX, typename StoreQuad,
+          typename Park = FusedNoPark, typename Unpark = FusedNoPark>
+__device__ __forceinline__ void ekf_step_fused_z(const DevParams<T>& p, const Noise<T>& nzl, T (&x)[16], const T (&Po)[120], const T (&u)[6],
+                                                 TagPose&& tag_pose, bool corr, bool live, EmitAccel&& emit_accel, EmitObs&& emit_obs,
+                                                 StoreX&& store_x, StoreQuad&& store_quad, Park&& park = Park(), Unpark&& unpark = Unpark())
 {
     using SQ = quad::ScalarQ<T>;
     constexpr int kPW_ = 120;
@@ -105,10 +133,29 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
 
     if (corr) {
         T V[15][6], NV[15][6];
+        park(x);
         static_for<0, kPW_>([&](auto wc) {   // a compile-time loop: every index below must be a constant (no array may reach scratch)
             constexpr int w = kPW_ - 1 - decltype(wc)::value;
             constexpr int i = word_row(w), k = word_col(w), b = i / 3;
             if constexpr (w == block_row_last_word(b)) {   // rows 3b .. 3b+2 of V = (P G^T) L^-T and of -V D^-1, from words not yet touched
+                // conventional method: Gx = Cc [Cc^T r]x (EKF.cpp:455-458) is formed again from the predicted nominal state for every
+                // block-row (five times ~30 operations) instead of nine values staying live through the whole sweep -- in fp64 they were
+                // most of what the kernel spilled (188 B per lane)
+                T gx[9];
+                if constexpr (!DIRECT) {
+                    T xl[16];
+                    if constexpr (std::remove_reference_t<Unpark>::parked) unpark(xl);
+                    else {
+#pragma unroll
+                        for (int kk = 0; kk < 16; ++kk) xl[kk] = x[kk];
+                    }
+#if defined(__HIP_DEVICE_COMPILE__)
+                    // opaque copies of the seven words Gx depends on, tied to a covariance word of THIS block-row: the backend would otherwise
+                    // fold the five evaluations back into one and keep its result alive
+                    asm volatile("" : "+v"(xl[0]), "+v"(xl[1]), "+v"(xl[2]), "+v"(xl[6]), "+v"(xl[7]), "+v"(xl[8]), "+v"(xl[9]) : "v"(Pn[w]));
+#endif
+                    conventional_gx<T>(xl, gx);
+                }
 #pragma unroll
                 for (int r = 0; r < 3; ++r) {
                     const int a = 3 * b + r;
@@ -117,7 +164,7 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
                     for (int kk = 0; kk < 3; ++kk) { v[kk] = Pn[sidx(a, kk)]; v[3 + kk] = Pn[sidx(a, 6 + kk)]; }
                     if (!DIRECT) {
 #pragma unroll
-                        for (int kk = 0; kk < 3; ++kk) v[kk] += v[3] * f.Gx[3 * kk] + v[4] * f.Gx[3 * kk + 1] + v[5] * f.Gx[3 * kk + 2];
+                        for (int kk = 0; kk < 3; ++kk) v[kk] += v[3] * gx[3 * kk] + v[4] * gx[3 * kk + 1] + v[5] * gx[3 * kk + 2];
                     }
 #pragma unroll
                     for (int m = 1; m < 6; ++m) {
@@ -135,11 +182,13 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
             Pn[w] = acc;
             if constexpr (w % 4 == 0) store_quad(std::integral_constant<int, w / 4>{}, &Pn[w]);
         });
+        unpark(x);
         // Nothing the downdate needs depends on the innovation: dy, its elimination yd = D^-1 L^-1 dy, dx and the injection come AFTER the
         // sweep, where they run under the drain of the covariance stores.  The tag pose is made to depend on the last covariance word so
         // that the scheduler cannot pull the chain (quaternion logarithm: ~150 dependent instructions) in front of the first store.
         {
-            T zz[7] = {z[0], z[1], z[2], z[3], z[4], z[5], z[6]};
+            T zz[7];
+            tag_pose(zz);
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(zz[6]) : "v"(Pn[0]));
 #endif
@@ -174,6 +223,17 @@ __device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Nois
             store_quad(std::integral_constant<int, q4>{}, &Pn[4 * q4]);
         });
     }
+}
+
+template <typename T, bool DIRECT, typename EmitAccel, typename EmitObs, typename StoreX, typename StoreQuad>
+__device__ __forceinline__ void ekf_step_fused(const DevParams<T>& p, const Noise<T>& nzl, T (&x)[16], const T (&Po)[120], const T (&u)[6],
+                                               const T (&z)[7], bool corr, bool live, EmitAccel&& emit_accel, EmitObs&& emit_obs,
+                                               StoreX&& store_x, StoreQuad&& store_quad)
+{
+    ekf_step_fused_z<T, DIRECT>(p, nzl, x, Po, u, [&](T (&zz)[7]) {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) zz[k] = z[k];
+    }, corr, live, emit_accel, emit_obs, store_x, store_quad);
 }
 
 }  // namespace qle

@@ -431,6 +431,23 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
     }
 }
 
+// The nominal state of a lane in / out of its column of an LDS array (step_tick: fp64 keeps x there during the covariance sweep).
+template <typename T, bool ON, bool LOAD>
+struct LdsPark {
+    static constexpr bool parked = ON;
+    T (*slot)[ON ? kBlock : 1];
+    __device__ __forceinline__ void operator()(T (&xx)[kXW]) const
+    {
+        if constexpr (ON) {
+#pragma unroll
+            for (int k = 0; k < kXW; ++k) {
+                if (LOAD) xx[k] = slot[k][threadIdx.x];
+                else slot[k][threadIdx.x] = xx[k];
+            }
+        }
+    }
+};
+
 // Fused tick (filter_update single-rate branch, EKF.cpp:238-249,265-290): predict, then correct where the record's mask word is
 // non-zero, as one straight-line schedule (ekf_step_fused, ekf_fused.hpp).
 // Reads x16 + P120 + u6 + z7 (+mask), writes x16 + P120 (285 words/filter).
@@ -467,7 +484,24 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
     T* tb = st + wave_tile(i) * (int64_t)(kSW * kTile);
     const int lane = (int)(i & 63);
     T Pc[kPWc];   // compact records only: written group by group in the final sweep (every pose-block word is in one), never otherwise
-    ekf_step_fused<T, DIRECT>(p, nz, x, Po, u, z, corr, !dead,
+    auto tag_pose = [&](T (&zz)[7]) {
+        if constexpr (sizeof(T) == 8) {   // fp64: read again where the innovation needs it (an L2 hit) instead of 14 registers held through the sweep
+            T zq[kZW];
+            load_rec<T, kZW, 0, kZW, NT>(zs, i, zq);
+#pragma unroll
+            for (int k = 0; k < 7; ++k) zz[k] = zq[k];
+        } else {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) zz[k] = z[k];
+        }
+    };
+    // fp64: the nominal state (16 values) waits out the covariance sweep in the LDS (32 KiB per workgroup); the conventional method reads
+    // r and q back from there for each block-row's Gx
+    constexpr bool kPark = sizeof(T) == 8;
+    __shared__ T parked[kPark ? kXW : 1][kPark ? kBlock : 1];
+    const LdsPark<T, kPark, false> park{parked};
+    const LdsPark<T, kPark, true> unpark{parked};
+    ekf_step_fused_z<T, DIRECT>(p, nz, x, Po, u, tag_pose, corr, !dead,
         [&](const T (&accel)[3]) {
             if (aux_accel && !dead) {   // optional side outputs (wave-uniform), written as soon as they exist
 #pragma unroll
@@ -494,7 +528,7 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
                 const int qr = kXW / VW + q4 * (4 / VW) + h;
                 st_quad<NtSt<NT>::value>(reinterpret_cast<Q*>(tb + (qr * kTile + lane) * VW), pack_quad(w4 + h * VW));
             }
-        });
+        }, park, unpark);
     if (COMPACT && !dead) {
 #pragma unroll
         for (int k = 45; k < kPWc; ++k) Pc[k] = T(0);
