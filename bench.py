@@ -444,10 +444,13 @@ def main():
             tj = json.load(open(tpath))
             key = f"{args.workload if args.workload != 'cfg4' else 'cfg3'}:{B}:{args.dtype}:{'step' if dom_step else 'predict'}"
             if key in tj.get("per_launch", {}):
-                traffic = tj["per_launch"][key]["hbm_bytes"]
+                traffic = tj["per_launch"][key].get("fabric_bytes", tj["per_launch"][key].get("hbm_bytes"))
                 traffic_src = {"file": "profiles/traffic.json", "measured_at_sha": tj.get("sha"), "kernel": tj["per_launch"][key].get("kernel"),
-                               "note": "2 x FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes (MI355X_MICROARCH.md HBM section); counts "
-                                       "L2<->fabric requests, Infinity-Cache hits included"}
+                               "note": "L2<->fabric bytes: 2 x FETCH_SIZE + WRITE_SIZE per launch, separate rocprofv3 --pmc passes (MI355X_MICROARCH.md HBM "
+                                       "section).  Infinity-Cache hits are included (no counter of this part separates them: the TCC_EA0_*_DRAM "
+                                       "counters count the requests to the local memory's address space, in front of the Infinity Cache -- "
+                                       "profiles/r04_pmc_dram_*.md), so this is HBM traffic only where the state cannot stay on die; it shows "
+                                       "that nothing is fetched or written twice"}
         except Exception:
             traffic = traffic_src = None
 
@@ -511,13 +514,15 @@ def main():
         # the HBM-served share of the same kernel where the state cannot stay on die: the split policy keeps split_k64/64 of the state
         # in the Infinity Cache, so only the rest of the algorithmic bytes comes from / goes to HBM in the measured time
         hr["hbm_share"] = 1.0 - hr["split_k64"] / 64.0
+        hr["hbm_share_is"] = "MODELLED, not counted: the split policy keeps split_k64/64 of the state cached; assumes that share is served entirely on die"
         hr["hbm_achieved"] = hr["hbm_share"] * hr["achieved"]
         hr["hbm_frac"] = hr["hbm_achieved"] / HBM_PEAK_GBS
         hr["hbm_frac_of_measured_copy"] = hr["hbm_achieved"] / HBM_COPY_GBS
         if out["roofline"]["hbm_frac"] is None:
             out["roofline"]["hbm_frac"] = hr["hbm_frac"]
+            out["roofline"]["hbm_frac_is"] = "modelled (hbm_share of the algorithmic bytes / time / 8 TB/s): an estimate, no counter separates Infinity-Cache hits from HBM"
             out["roofline"]["hbm_frac_source"] = ("hbm_resident: k_predict<float> on %d filters (%.0f MiB of state), (1 - split_k64/64) x algorithmic bytes / "
-                                                  "HIP-event kernel time / 8 TB/s; rocprofv3 durations: profiles/r03_kernel_stats_b2097152.md" % (hr["batch"], hr["state_MiB"]))
+                                                  "HIP-event kernel time / 8 TB/s; rocprofv3 durations: profiles/r04_kernel_stats_b2097152.md" % (hr["batch"], hr["state_MiB"]))
     if rank == 0:
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:

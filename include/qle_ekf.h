@@ -83,7 +83,8 @@ typedef struct qle_params {
     double tag_in_view_margin;                 /* EKF.hpp:118 */
     double tag_widths[QLE_MAX_TAGS];           /* EKF.hpp:120 */
     double tag_positions[3 * QLE_MAX_TAGS];    /* EKF.hpp:121, x,y,z per tag (NODE.cpp:130-136) */
-    double small_ang_tol;                      /* EKF.hpp:131 */
+    double small_ang_tol;                      /* EKF.hpp:131; must be <= 1e-8: the engine evaluates the exact series at every angle
+                                                  (equal to the reference's small-angle forms there), larger values are refused */
     double g[3];                               /* EKF.hpp:132 */
 } qle_params;
 

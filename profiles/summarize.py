@@ -49,10 +49,11 @@ def traffic(fetch_dir, write_dir, key, kernel_re, out_json):
         if tj.get("sha") != SHA:      # measurements of another head do not mix
             tj = {"per_launch": {}}
     tj["sha"] = SHA
-    tj["units"] = "bytes per launch; hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 reports KiB; FETCH_SIZE doubled per the gfx950 note)"
+    tj["units"] = ("bytes per launch; fabric_bytes = 2 x FETCH_SIZE + WRITE_SIZE (rocprofv3 reports KiB; FETCH_SIZE doubled per the gfx950 note): what "
+                   "the L2s exchange with the fabric, Infinity-Cache hits included -- HBM bytes only where the state cannot stay on die")
     tj["per_launch"][key] = {"kernel": got["FETCH_SIZE"][2][:100], "fetch_size_kib": fetch_kib, "write_size_kib": write_kib,
                              "dispatches": [got["FETCH_SIZE"][1], got["WRITE_SIZE"][1]],
-                             "hbm_bytes": 2 * fetch_kib * 1024 + write_kib * 1024}
+                             "fabric_bytes": 2 * fetch_kib * 1024 + write_kib * 1024}
     json.dump(tj, open(out_json, "w"), indent=1)
     print("traffic", key, tj["per_launch"][key])
 

@@ -5,7 +5,7 @@ filter, one whose mask is all zero, and a predict-only tick.
     [QLE_QUAD=0|1|2|3|7] [QLE_LIB=...] [QLE_TIME_DIRECT=0] python profiles/time_kernels.py <batch> <f32|f64> [label]
 
 QLE_TIME_DIRECT=0 times the conventional orientation method (direct_orien_method = 0, the reference's default, EKF.cpp:440-444);
-QLE_TIME_EST_BIAS=0 the 9-state filter (est_bias = false, EKF.cpp:92; compact records from 32 768 filters up, QLE_COMPACT=0|1 forces).
+QLE_TIME_EST_BIAS=0 the 9-state filter (est_bias = false, EKF.cpp:92; compact records wherever the lane-per-filter kernels serve every tick, i.e. above 4 096 filters; QLE_COMPACT=0|1 forces).
 """
 import json
 import os

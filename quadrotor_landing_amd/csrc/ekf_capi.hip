@@ -70,6 +70,13 @@ extern "C" int qle_params_derive(const qle_params* p, qle_derived* d)
     if (!p || !d) return fail(QLE_ERR_INVALID, "null argument");
     if (!(p->update_freq > 0.0) || !(p->measurement_freq > 0.0)) return fail(QLE_ERR_INVALID, "update_freq and measurement_freq must be > 0");
     if (p->n_tags < 0 || p->n_tags > QLE_MAX_TAGS) return fail(QLE_ERR_INVALID, "n_tags out of range [0,%d]", QLE_MAX_TAGS);
+    // small_ang_tol (EKF.hpp:131): below it the reference switches exp / log / F[th,th] to first-order forms (QH.cpp:19-24, :44-49,
+    // EKF.cpp:385-389).  The engine evaluates the full series at every angle, which agrees with those forms to 1e-20 at the
+    // reference's 1e-10 and stops agreeing as the tolerance grows (4e-7 in the covariance at 1e-3): a larger value is refused rather than
+    // silently ignored.
+    if (!(p->small_ang_tol >= 0.0) || p->small_ang_tol > 1e-8)
+        return fail(QLE_ERR_INVALID, "small_ang_tol = %g is not supported: the engine evaluates the exact series at every angle, which matches the "
+                                     "reference's small-angle forms only for tolerances <= 1e-8 (reference default 1e-10)", p->small_ang_tol);
     std::memset(d, 0, sizeof(*d));
     d->dT_nom = 1.0 / p->update_freq;                                               // :90
     d->upd_per_meas = (int32_t)std::ceil(p->update_freq / p->measurement_freq);     // :91
@@ -229,6 +236,18 @@ static void choose_cache_policy(qle_batch* h)
         const int k64 = (int)std::lround(64.0 * 216.0 / std::max(state_mib, 1.0));
         h->split = -std::min(63, std::max(1, k64));
         if (state_mib > 64.0 * 240.0) h->nt = 2;       // even 1/64 of it would not fit: stream everything
+        // QLE_CHUNK=n (experiments; profiles/r04_tuning.md section 4): the lane-per-filter single-rate ticks are launched n filters at a time and
+        // the cache policy is the one of an n-filter state
+        h->chunk = 0;
+        if (const char* s = std::getenv("QLE_CHUNK")) {
+            const int64_t c = std::atoll(s);
+            if (c >= 256 && c % 256 == 0 && c < h->B) {
+                h->chunk = c;
+                const double chunk_mib = (double)(h->compact ? kXW + kPWc : kSW) * (double)c * (double)h->wsz / (1024.0 * 1024.0);
+                h->nt = chunk_mib <= 48.0 ? 1 : (chunk_mib <= 300.0 ? 0 : 3);
+                h->nt_refresh = chunk_mib <= 40.0 ? 128 : 0;
+            }
+        }
         if (const char* s = std::getenv("QLE_NT")) h->nt = std::min(3, std::max(0, std::atoi(s)));
         if (const char* s = std::getenv("QLE_SPLIT")) h->split = std::atoi(s);
     }
@@ -799,7 +818,7 @@ extern "C" int qle_get_report(qle_batch* h, double* pose, double* pose_cov, doub
 template <typename T>
 static int nonfinite_t(qle_batch* h)
 {
-    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)state_cur(h), h->counter, h->B);
+    hipLaunchKernelGGL((k_count_nonfinite<T>), grid_for(h, 256), dim3(256), 0, h->stream, (const T*)state_cur(h), h->counter, h->B, h->compact ? kXW + kPWc : kXW + kPW);
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }

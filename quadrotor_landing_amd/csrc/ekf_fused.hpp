@@ -142,7 +142,11 @@ __device__ __forceinline__ void ekf_step_fused_z(const DevParams<T>& p, const No
                 // block-row (five times ~30 operations) instead of nine values staying live through the whole sweep -- in fp64 they were
                 // most of what the kernel spilled (188 B per lane)
                 T gx[9];
-                if constexpr (!DIRECT) {
+                if constexpr (!DIRECT && sizeof(T) == 4) {   // fp32 has the registers: Gx as the factor step left it
+#pragma unroll
+                    for (int kk = 0; kk < 9; ++kk) gx[kk] = f.Gx[kk];
+                }
+                if constexpr (!DIRECT && sizeof(T) == 8) {
                     T xl[16];
                     if constexpr (std::remove_reference_t<Unpark>::parked) unpark(xl);
                     else {

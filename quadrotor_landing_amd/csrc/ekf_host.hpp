@@ -54,6 +54,7 @@ struct qle_batch {
     int32_t split = 0;        // nt == 3: which workgroups keep their tiles cached (cached_workgroup() in ekf_kernels.hpp)
     int32_t nt_refresh = 0;   // > 0: nt == 1 and the state is <= 40 MiB: non-temporal stores, cached-store tick every nt_refresh ticks
     int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal, 3 split
+    int64_t chunk = 0;     // > 0: the lane-per-filter single-rate ticks are launched in chunks of this many filters (choose_cache_policy)
     int32_t quad = 0;      // workgroup-cooperative tick kernel (ekf_quad_kernels.hpp): bit 0 ticks with tag poses, bit 1 predict-only ticks
     size_t wsz = 4;
     qle_params pub;
@@ -141,6 +142,15 @@ template <> const DevParams<float>& dev<float>(const qle_batch* h) { return h->p
 template <> const DevParams<double>& dev<double>(const qle_batch* h) { return h->pd; }
 
 static inline dim3 grid_for(const qle_batch* h, int block) { return dim3((unsigned)((h->B + block - 1) / block)); }
+// One tick as a sequence of launches over [i0, end): the whole batch at once, or h->chunk filters at a time.
+template <typename F> static inline void for_chunks(const qle_batch* h, int block, F&& launch)
+{
+    const int64_t step = h->chunk > 0 ? h->chunk : h->B;
+    for (int64_t i0 = 0; i0 < h->B; i0 += step) {
+        const int64_t end = std::min(h->B, i0 + step);
+        launch(dim3((unsigned)((end - i0 + block - 1) / block)), i0, end);
+    }
+}
 
 static inline size_t slot_bytes(const qle_batch* h) { return (size_t)kSW * (size_t)h->Bp * h->wsz; }
 // the state: one record array, updated in place by every tick
@@ -245,7 +255,9 @@ static inline void mr_schedule_extra(qle_batch* h)
     const int64_t e = n + period - step;
     // only an entry that lies AFTER this tick is worth a copy (a longer delay than the cadence puts it inside the replayed range,
     // one tick after the anchor), and only while the cadence is short enough for the IMU ring to still hold the samples
-    h->e_want = (e > n && period > 1 && period + step < h->mr_Cu) ? e : -1;
+    // (per-filter stamps with dynamic_meas_delay: every filter has its own step delay, the fixed-step guess serves none of them reliably)
+    const bool per_filter_delays = h->pub.dynamic_meas_delay && h->have_stamps;
+    h->e_want = (e > n && period > 1 && period + step < h->mr_Cu && !per_filter_delays) ? e : -1;
 }
 
 // ---- kernel launchers, defined and explicitly instantiated for float and double in the tu_*.hip files ----

@@ -419,9 +419,9 @@ __device__ __forceinline__ bool cached_workgroup(int32_t split)
 template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
-                                                       T* __restrict__ hist_ck, int64_t B, int32_t split, int32_t ck_cached)
+                                                       T* __restrict__ hist_ck, int64_t B, int32_t split, int32_t ck_cached, int64_t i0)
 {
-    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
+    const int64_t i = i0 + batch_block() * blockDim.x + threadIdx.x;   // i0: first filter of this launch (a tick may be launched in chunks)
     if (i >= B) return;
     if (NT == 3) {
         if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
@@ -495,9 +495,9 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
             for (int k = 0; k < 7; ++k) zz[k] = z[k];
         }
     };
-    // fp64: the nominal state (16 values) waits out the covariance sweep in the LDS (32 KiB per workgroup); the conventional method reads
-    // r and q back from there for each block-row's Gx
-    constexpr bool kPark = sizeof(T) == 8;
+    // fp64, conventional orientation method: the nominal state (16 values) waits out the covariance sweep in the LDS (32 KiB per workgroup)
+    // and r and q are read back from there for each block-row's Gx -- with that the kernel needs no scratch (was 140-250 B per lane)
+    constexpr bool kPark = sizeof(T) == 8 && !DIRECT;   // the direct method fits without (256 + 215 registers) and is 1.7 us faster so (28.5 vs 26.8 us)
     __shared__ T parked[kPark ? kXW : 1][kPark ? kBlock : 1];
     const LdsPark<T, kPark, false> park{parked};
     const LdsPark<T, kPark, true> unpark{parked};
@@ -540,9 +540,9 @@ template <typename T, bool DIRECT, bool PFP, bool GATE, int NT, bool COMPACT = f
 __global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
                                                  const T* __restrict__ zs, const T* __restrict__ pfp,
                                                  T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
+                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split, int64_t i0)
 {
-    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
+    const int64_t i = i0 + batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {   // see k_predict
         if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0, COMPACT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
@@ -1213,12 +1213,12 @@ __global__ void k_report_off(DevParams<T> p, const T* __restrict__ st, const T* 
 }
 
 template <typename T>
-__global__ void k_count_nonfinite(const T* __restrict__ st, unsigned long long* __restrict__ out, int64_t B)
+__global__ void k_count_nonfinite(const T* __restrict__ st, unsigned long long* __restrict__ out, int64_t B, int record_words)
 {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B) return;
     bool bad = false;
-    for (int w = 0; w < kSW; ++w) bad |= !isfinite((double)st[word_off<T>(w, i, kSW)]);
+    for (int w = 0; w < record_words; ++w) bad |= !isfinite((double)st[word_off<T>(w, i, kSW)]);   // the words a tick reads (64 in compact records)
     if (bad) atomicAdd(out, 1ULL);
 }
 

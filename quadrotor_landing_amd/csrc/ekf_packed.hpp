@@ -21,8 +21,9 @@
 //     state needs anyway (EKF.cpp:367): one half-angle sine / cosine per tick, as branch-free polynomials for |phi|/2 <= pi/4 (any
 //     physical rate: 0.79 rad per tick) with the libm path behind a wave-level branch beyond.  The small-angle branches of the
 //     reference (QH.cpp:19-28, EKF.cpp:385-389) are the same series truncated; they agree to 1e-20.
-// ~560 instructions per tick in fp32 (of which ~330 packed) against ~1 370.  fp64 runs the same code with two-element vectors the
-// compiler splits into v_fma_f64 (no packed fp64 FMA exists): same count as scalar code, but no libm calls and no second P.
+// ~900 instructions per tick in fp32 (of which ~330 packed) against ~1 370.  Device code runs the block form in fp32 only (k_step_mr<float>);
+// the fp64 replay keeps its covariance split between the LDS and registers (ekf_split.hpp) and the on-chip-resident kernel runs the in-place
+// congruences of ekf_device.hpp.  The host build (test suite) instantiates the block form in both dtypes.
 #pragma once
 
 #include "ekf_device.hpp"
@@ -357,40 +358,10 @@ __device__ __forceinline__ void packed_cov_predict(const PackedCtx<T>& c, const 
     }
 }
 
-// prediction_step, EKF.cpp:346-415, on the packed triangle (in place, scalar congruences of ekf_device.hpp) with the scalar part above:
-// the form the fp64 replay loop runs.
-template <typename T>
-__device__ __forceinline__ void ekf_predict_lean(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], T (&P)[120], const T (&u)[6], T (&accel)[3])
-{
-    PackedCtx<T> c;
-    packed_nominal<T>(p, nz, x, u, accel, c);
-    PredictCtx<T> s;
-    s.dT = c.dT; s.dTw = c.dTw;
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int m = 0; m < 3; ++m) {
-            s.X[i][m] = c3_el(c.CA, i, m);
-            s.X[i][3 + m] = c3_el(c.CB, i, m);
-            s.Rt[i][m] = c3_el(c.CR, i, m);
-        }
-    }
-    // W Q W^T is added from CQC instead of C: predict_cov_inplace forms C Qa C^T from s.C, so hand it a C whose product is CQC
-    predict_cov_inplace_noq<T>(s, P);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-#pragma unroll
-        for (int k = i; k < 3; ++k) P[sidx(3 + i, 3 + k)] += m3_elA(c.CQC, i, k);
-        P[sidx(6 + i, 6 + i)] += nz.Q[3 + i];
-        P[sidx(9 + i, 9 + i)] += nz.Q[6 + i];
-        P[sidx(12 + i, 12 + i)] += nz.Q[9 + i];
-    }
-}
-
-// prediction_step, EKF.cpp:346-415, on the blocks.  Device code instantiates it for fp32 only: fp64 has no packed FMA to gain, the full
-// diagonal blocks cost 30 registers more than the packed triangle, and the one fp64 instantiation that was built (k_step_mr<double>
-// on two-element double vectors: 1.5 KB of scratch per lane) ended in a GPU memory fault on its first launch -- the fp64 kernels run
-// ekf_predict_lean above.  The host build (test suite) runs both dtypes.
+// prediction_step, EKF.cpp:346-415, on the blocks.  Device code instantiates it for fp32 only: fp64 has no packed FMA to gain and the full
+// diagonal blocks cost 30 registers more than the packed triangle (the one fp64 instantiation that was built, round 3, spilled 1.5 KB per
+// lane; its GPU memory fault was the backend's, see profiles/r04_tuning.md section 1) -- the fp64 replay runs ekf_split.hpp.  The host
+// build (test suite) runs both dtypes.
 template <typename T>
 __device__ __forceinline__ void ekf_predict_packed(const DevParams<T>& p, const Noise<T>& nz, T (&x)[16], PackedCov<T>& S, const T (&u)[6], T (&accel)[3])
 {

@@ -75,6 +75,14 @@ def test_params_validation_errors():
     p = qla.default_params(); p.n_tags = 99
     with pytest.raises(qla.QleError):
         qla.derive(p)
+    # small_ang_tol (EKF.hpp:131): the engine evaluates the exact series at every angle, equal to the reference's small-angle forms at
+    # its 1e-10; a tolerance at which the reference's first-order forms would differ is refused, not silently ignored
+    p = qla.default_params(); p.small_ang_tol = 1e-3
+    with pytest.raises(qla.QleError) as e:
+        qla.derive(p)
+    assert e.value.code == _lib.QLE_ERR_INVALID and "small_ang_tol" in str(e.value)
+    p = qla.default_params(); p.small_ang_tol = 1e-9
+    qla.derive(p)
 
 
 def test_yaml_loader_reads_reference_key_names(tmp_path):
