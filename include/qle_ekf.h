@@ -262,6 +262,26 @@ int qle_synth_get_truth(qle_batch *h, const qle_inputs *in, double *pose, double
  * bias = [batch][6] = ab_nom+ab_static, wb_nom+wb_static (NODE.cpp:215-220).
  * Any pointer may be NULL. */
 int qle_get_report(qle_batch *h, double *pose, double *pose_cov, double *vel, double *bias);
+/* Everything the node puts on the wire after a tick (NODE.cpp:192-281), one struct per filter, in ONE call:
+ * rel_pose_state (pose + the 6x6 pose covariance, :192-211), rel_vel_state (:212-214), IMU_bias (:215-220), rel_accel (:222-226,
+ * zero unless qle_enable_aux), upds_since_correction (:228-232) and, on a tick that corrected, the observation it fused and
+ * measurement_delay_curr (:240-275).  The flag and counter fields need qle_enable_gating (else 0 / -1); the delay needs the
+ * multirate EKF (else 0).  `out` holds batch structs. */
+typedef struct qle_node_report {
+    double pose[7];                 /* r_nom, q_nom (x,y,z,w) */
+    double pose_cov[36];            /* rows/cols {0-2, 6-8} of cov_pert, row-major */
+    double vel[3];                  /* v_nom */
+    double accel[3];                /* accel_rel */
+    double bias[6];                 /* ab_nom + ab_static, wb_nom + wb_static */
+    double obs[7];                  /* r_t_vt_obs, q_tv_obs of the correction this tick performed */
+    double measurement_delay_curr;  /* EKF.hpp:86 */
+    int32_t upds_since_correction;  /* EKF.hpp:128; -1 without gating */
+    uint8_t performed_correction;   /* EKF.hpp:126 */
+    uint8_t measurement_consumed;   /* the tick cleared measurement_ready (EKF.cpp:186) */
+    uint8_t state_initialized;      /* EKF.hpp:125 */
+    uint8_t reserved;
+} qle_node_report;
+int qle_get_node_report(qle_batch *h, qle_node_report *out);
 /* Number of filters whose x or P holds a NaN/Inf. */
 int qle_count_nonfinite(qle_batch *h, int64_t *count);
 

@@ -55,6 +55,13 @@ class QleSynthCfg(C.Structure):
     ]
 
 
+class QleNodeReport(C.Structure):
+    """`struct qle_node_report`: what the node publishes after a tick (NODE.cpp:192-281), one per filter."""
+    _fields_ = [("pose", _d * 7), ("pose_cov", _d * 36), ("vel", _d * 3), ("accel", _d * 3), ("bias", _d * 6), ("obs", _d * 7),
+                ("measurement_delay_curr", _d), ("upds_since_correction", _i32), ("performed_correction", C.c_uint8),
+                ("measurement_consumed", C.c_uint8), ("state_initialized", C.c_uint8), ("reserved", C.c_uint8)]
+
+
 class QlePolicy(C.Structure):
     """`struct qle_policy`: how a handle launches its ticks."""
     _fields_ = [("state_policy", _i32), ("refresh_period", _i32), ("split_k64", _i32), ("block", _i32), ("coop_ticks", _i32),
@@ -112,6 +119,7 @@ SYMBOLS = {
     "qle_synth_rmse": (C.c_int, [_vp, _vp, _pd]),
     "qle_synth_get_truth": (C.c_int, [_vp, _vp, _pd, _pd]),
     "qle_get_report": (C.c_int, [_vp, _pd, _pd, _pd, _pd]),
+    "qle_get_node_report": (C.c_int, [_vp, C.POINTER(QleNodeReport)]),
     "qle_count_nonfinite": (C.c_int, [_vp, C.POINTER(_i64)]),
     "qle_synchronize": (C.c_int, [_vp]),
     "qle_timer_begin": (C.c_int, [_vp]),

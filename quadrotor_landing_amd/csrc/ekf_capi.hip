@@ -714,6 +714,40 @@ static int upds_since_t(qle_batch* h, int32_t* d_out)
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
+// NODE.cpp:192-281 in one call: the gathers above composed into one struct per filter (host side; the device work is theirs).
+extern "C" int qle_get_node_report(qle_batch* h, qle_node_report* out)
+{
+    QLE_TRY(check_handle(h));
+    if (!out) return fail(QLE_ERR_INVALID, "out is null");
+    QLE_GUARD_BEGIN
+    const size_t B = (size_t)h->B;
+    std::vector<double> pose(B * 7), cov(B * 36), vel(B * 3), bias(B * 6), acc(B * 3, 0.0), obs(B * 7, 0.0), dly(B, 0.0);
+    std::vector<uint8_t> pc(B, 0), co(B, 0), init(B, 0);
+    std::vector<int32_t> ups(B, -1);
+    QLE_TRY(qle_get_report(h, pose.data(), cov.data(), vel.data(), bias.data()));
+    QLE_TRY(qle_get_state_initialized(h, init.data()));
+    if (h->aux) QLE_TRY(qle_get_aux(h, acc.data(), obs.data()));
+    if (h->last_corr) QLE_TRY(qle_get_tick_flags(h, pc.data(), co.data(), ups.data()));
+    if (h->mr) QLE_TRY(qle_get_measurement_delay(h, dly.data()));
+    for (size_t i = 0; i < B; ++i) {
+        qle_node_report& r = out[i];
+        std::memcpy(r.pose, &pose[i * 7], sizeof(r.pose));
+        std::memcpy(r.pose_cov, &cov[i * 36], sizeof(r.pose_cov));
+        std::memcpy(r.vel, &vel[i * 3], sizeof(r.vel));
+        std::memcpy(r.accel, &acc[i * 3], sizeof(r.accel));
+        std::memcpy(r.bias, &bias[i * 6], sizeof(r.bias));
+        std::memcpy(r.obs, &obs[i * 7], sizeof(r.obs));
+        r.measurement_delay_curr = dly[i];
+        r.upds_since_correction = ups[i];
+        r.performed_correction = pc[i];
+        r.measurement_consumed = co[i];
+        r.state_initialized = init[i];
+        r.reserved = 0;
+    }
+    return QLE_OK;
+    QLE_GUARD_END
+}
+
 extern "C" int qle_get_tick_flags(qle_batch* h, uint8_t* performed_correction, uint8_t* consumed, int32_t* upds_since_correction)
 {
     QLE_TRY(check_handle(h));

@@ -266,6 +266,14 @@ class BatchedRelativePoseEKF:
         check(lib().qle_get_report(self._h, _dp(pose), _dp(cov), _dp(vel), _dp(bias)))
         return {"pose": pose, "pose_cov": cov.reshape(B, 6, 6), "vel": vel, "bias": bias}
 
+    def node_report(self):
+        """Everything the node publishes after a tick (relative_pose_EKF_node.cpp:192-281) in one call: a numpy record array
+        with one entry per filter (fields of `struct qle_node_report`)."""
+        from ._lib import QleNodeReport
+        buf = (QleNodeReport * self.batch)()
+        check(lib().qle_get_node_report(self._h, buf))
+        return np.ctypeslib.as_array(buf).copy() if hasattr(np.ctypeslib, "as_array") else np.frombuffer(buf, dtype=np.dtype(QleNodeReport)).copy()
+
     def count_nonfinite(self):
         c = C.c_int64(0)
         check(lib().qle_count_nonfinite(self._h, C.byref(c)))

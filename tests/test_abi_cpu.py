@@ -38,6 +38,7 @@ def test_struct_layouts_match_header_sizes():
     assert C.sizeof(_lib.QleParams) == 8 * 5 + 4 * 6 + 8 * 5 + 8 * (12 + 6 + 6 + 3 + 4 + 9) + 4 * 4 + 8 * (1 + 16 + 48 + 1 + 3)
     assert C.sizeof(_lib.QleDerived) == 8 + 16 + 8 * (12 + 6 + 15 + 4 + 9)
     assert C.sizeof(_lib.QleSynthCfg) == 8 * 6 + 8 + 8   # ... two int32, view_scale
+    assert C.sizeof(_lib.QleNodeReport) == 8 * (7 + 36 + 3 + 3 + 6 + 7 + 1) + 4 + 4
 
 
 def test_params_default_and_derive_match_oracle():

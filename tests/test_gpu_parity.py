@@ -359,6 +359,27 @@ def test_initialize_state_and_report(dtype, tol):
     np.testing.assert_array_equal(rep["pose_cov"], Ps[:, sel][:, :, sel])
     np.testing.assert_array_equal(rep["vel"], xs[:, 3:6])
     np.testing.assert_allclose(rep["bias"], xs[:, 10:16] + np.array(HW["ab_static"] + HW["wb_static"]), atol=1e-7)
+    # the same and the rest of what the node puts on the wire (NODE.cpp:192-281) through the one-call struct, after a gated tick
+    ekf.enable_gating(True)
+    ekf.enable_aux(True)
+    u = rng.normal(size=(B, 6)) * 0.1 + np.array([0, 0, 9.8, 0, 0, 0])
+    ready = (np.arange(B) % 3 != 0).astype(np.uint8)
+    ekf.filter_update(u, z, ready)
+    nr = ekf.node_report()
+    rep = ekf.report()
+    pc, co, up = ekf.tick_flags()
+    acc, obs = ekf.get_aux()
+    np.testing.assert_array_equal(nr["pose"], rep["pose"])
+    np.testing.assert_array_equal(nr["pose_cov"].reshape(B, 6, 6), rep["pose_cov"])
+    np.testing.assert_array_equal(nr["vel"], rep["vel"])
+    np.testing.assert_array_equal(nr["bias"], rep["bias"])
+    np.testing.assert_array_equal(nr["accel"], acc)
+    np.testing.assert_array_equal(nr["obs"], obs)
+    np.testing.assert_array_equal(nr["performed_correction"], pc)
+    np.testing.assert_array_equal(nr["measurement_consumed"], co)
+    np.testing.assert_array_equal(nr["upds_since_correction"], up)
+    assert nr["state_initialized"].all() and (nr["measurement_consumed"] == ready).all()
+    assert (nr["measurement_delay_curr"] == 0).all()      # single-rate filter
     ekf.close()
 
 
