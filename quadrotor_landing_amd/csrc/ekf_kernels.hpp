@@ -34,6 +34,15 @@ namespace qle {
 #ifndef QLE_RING_POLICY
 #define QLE_RING_POLICY 2
 #endif
+// How many replayed ticks ahead k_step_mr requests its stored IMU samples (1..4).  Measured at 1 / 2 / 3 / 4 (profiles/r04_tuning.md section 8):
+// k_step_mr<float> 40.2 / 41.6 / 40.5 / 41.6 us, <double> 89.6 / 90.9 / 91.4 / 91.8 -- one is enough, the anchor's stores do not hold the
+// replay up.
+#ifndef QLE_MR_PREFETCH_F32
+#define QLE_MR_PREFETCH_F32 1
+#endif
+#ifndef QLE_MR_PREFETCH_F64
+#define QLE_MR_PREFETCH_F64 1
+#endif
 constexpr int kBlock = 256;
 constexpr int kTile = 64;   // filters per tile = wavefront size
 
@@ -647,6 +656,24 @@ __device__ __forceinline__ int32_t wave_min_i32(int32_t v)
     return __builtin_amdgcn_readfirstlane(v);
 }
 
+// The stored IMU sample of tick ts (wave-uniform) into dst: from the ring, or -- the current tick's own -- from the input record; a tick
+// beyond the current one has none.
+template <typename T>
+__device__ __forceinline__ void mr_request_sample(const MrParams& m, T* uring, const T* __restrict__ us, int64_t i, int32_t ts, T (&dst)[kUW])
+{
+    if (ts < m.tick) {
+        T ur[kHW];
+        load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, ts), i, ur);
+#pragma unroll
+        for (int k = 0; k < kUW; ++k) dst[k] = ur[k];
+    } else if (ts == m.tick) {
+        T uc[kUW];
+        load_rec<T, kUW, 0, kUW>(us, i, uc);
+#pragma unroll
+        for (int k = 0; k < kUW; ++k) dst[k] = uc[k];
+    }
+}
+
 // A multirate tick that carries tag poses.  Lanes that correct: load the newest checkpoint at or before the entry the
 // measurement belongs to (or the anchor), replay up to that entry, fuse the measurement there (the corrected entry becomes the
 // anchor), replay the predictions up to n-1 from the stored IMU samples -- rewriting the checkpoints on the way -- then predict
@@ -854,6 +881,20 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     // fp32, regular cadence: every lane's chain starts AT its measurement's entry (the extra checkpoint).  The correction then runs on the
     // loaded triangle directly -- its scalar chains (innovation, R_k) under the tail of the 36 MB load, no pack / unpack round trip through
     // the register blocks in front of it -- and the loop below finds nothing left to correct (wave-uniform choice).
+    // The IMU samples of the next kQ replayed ticks are requested ahead (wave-uniform slot addresses), the first kQ in front of the
+    // correction.  kQ = 1 ships: one step of arithmetic (~1.8 us) covers the latency of the ring, which was streamed to HBM; deeper queues
+    // (the idea: a sample requested behind the 36 / 72 MB of anchor stores is not delivered before they have drained) measured no gain, and
+    // requesting the whole window up front (LDS-DMA, profiles/r03_tuning.md) made the prologue 15 000 cycles longer.
+    // A sample index beyond the current tick has no request; the current tick's own sample comes from `us` (it is asked for again here so
+    // that it is not carried in registers through the whole replay).
+    constexpr int kQ = sizeof(T) == 4 ? QLE_MR_PREFETCH_F32 : QLE_MR_PREFETCH_F64;
+    static_assert(kQ >= 1 && kQ <= 4, "the sample queue is four named register arrays");
+    T un0[kUW], un1[kUW], un2[kUW], un3[kUW];   // separate arrays: a [kQ][kHW] array was left in scratch by the backend
+    auto request_sample = [&](int32_t ts, T (&dst)[kUW]) { mr_request_sample<T>(m, uring, us, i, ts, dst); };   // ts is wave-uniform
+    request_sample(t_lo + 1, un0);
+    if constexpr (kQ > 1) request_sample(t_lo + 2, un1);
+    if constexpr (kQ > 2) request_sample(t_lo + 3, un2);
+    if constexpr (kQ > 3) request_sample(t_lo + 4, un3);
     bool early = false;
     if (sp != cur) load_rec<T, kSW, 0, kXW>(sp, i, x);
     if constexpr (sizeof(T) == 4) {
@@ -872,18 +913,6 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
     } else {
         S.load_cov(sp, i);
         QLE_STAMP(3, S.probe() + x[0]);
-    }
-    // The IMU sample of the NEXT replayed tick is requested one step ahead (wave-uniform slot address).  One step of arithmetic (~1.8 us)
-    // covers the latency of the ring, which was streamed to HBM; requesting the whole window up front instead (LDS-DMA into a per-wave LDS
-    // window, profiles/r03_tuning.md) made the loop 4 % shorter and the prologue 15 000 cycles longer: the requests of all waves arrive
-    // at once and queue behind one another.
-    // The current tick's own sample joins the same chain of one-ahead requests (it is asked for again while the last replayed tick is
-    // computed) so that it is not carried in registers through the whole replay.
-    T un[kHW];
-    if (t_lo + 1 < m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t_lo + 1), i, un);
-    else {
-#pragma unroll
-        for (int k = 0; k < kUW; ++k) un[k] = u[k];
     }
     // The chain.  Two copies of the loop: the first runs up to the last entry any lane of the wave corrects at (wave-uniform t_cmax) with
     // the correction inside; the second takes the rest -- after that tick nothing of the correction (the tag pose, R, its temporaries) is
@@ -905,15 +934,18 @@ __global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams g
         const bool now = t == m.tick;                         // wave-uniform
         T u6[kUW];
 #pragma unroll
-        for (int k = 0; k < kUW; ++k) u6[k] = un[k];
+        for (int k = 0; k < kUW; ++k) u6[k] = un0[k];
         QLE_STAMP(8 + 2 * dbg_j, u6[0] + u6[5]);
-        if (t + 1 < m.tick) load_rec<T, kHW, 0, kHW>(mr_u_slot(uring, m, t + 1), i, un);
-        else if (t + 1 == m.tick) {
-            T uc[kUW];
-            load_rec<T, kUW, 0, kUW>(us, i, uc);
 #pragma unroll
-            for (int k = 0; k < kUW; ++k) un[k] = uc[k];
+        for (int k = 0; k < kUW; ++k) {
+            if constexpr (kQ > 1) un0[k] = un1[k];
+            if constexpr (kQ > 2) un1[k] = un2[k];
+            if constexpr (kQ > 3) un2[k] = un3[k];
         }
+        if constexpr (kQ == 1) request_sample(t + 1, un0);
+        else if constexpr (kQ == 2) request_sample(t + 2, un1);
+        else if constexpr (kQ == 3) request_sample(t + 3, un2);
+        else request_sample(t + 4, un3);
         if (valid && t > start) {
             if constexpr (sizeof(T) == 8 && PFP) load_noise<T, PFP>(p, pfp, i, nz);   // fp64: 24 values read again (L2) rather than 48 registers held through the loop
             S.predict(p, nz, x, u6, accel);

@@ -61,6 +61,20 @@ namespace qle { static __device__ unsigned long long qle_dbg_split_clock[4096 * 
 #ifndef QLE_PREDICT_FENCES
 #define QLE_PREDICT_FENCES 0
 #endif
+// fences of the correction: 2 = between every 3 x 3 block of the LDS rows, 1 = between block-rows and halves only, 0 = none
+#ifndef QLE_UPDATE_FENCES
+#define QLE_UPDATE_FENCES 2
+#endif
+#if QLE_UPDATE_FENCES >= 2
+#define QLE_BLOCK_FENCE() QLE_PHASE_FENCE()
+#else
+#define QLE_BLOCK_FENCE() do { } while (0)
+#endif
+#if QLE_UPDATE_FENCES >= 1
+#define QLE_UPDATE_FENCE() QLE_PHASE_FENCE()
+#else
+#define QLE_UPDATE_FENCE() do { } while (0)
+#endif
 #if QLE_PREDICT_FENCES
 #define QLE_PREDICT_FENCE() QLE_PHASE_FENCE()
 #else
@@ -398,7 +412,7 @@ __host__ __device__ __forceinline__ void ekf_update_split(const DevParams<T>& p,
     }
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        QLE_PHASE_FENCE();
+        QLE_UPDATE_FENCE();
         if (half == 1) {   // the th columns of P1, less V1 Cx, take V1's place row by row
 #pragma unroll
             for (int a = 0; a < 15; ++a) {
@@ -425,7 +439,7 @@ __host__ __device__ __forceinline__ void ekf_update_split(const DevParams<T>& p,
         // P(i, k) += sum_m (-V(i, m) / d_m) V(k, m), block-row by block-row; the LDS rows pass through registers one block at a time
 #pragma unroll
         for (int b = 0; b < 5; ++b) {
-            QLE_PHASE_FENCE();
+            QLE_UPDATE_FENCE();
             T NV[3][3];
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
@@ -434,7 +448,7 @@ __host__ __device__ __forceinline__ void ekf_update_split(const DevParams<T>& p,
             }
 #pragma unroll
             for (int c = b; c < 5; ++c) {
-                if (b < 2 && c > b) QLE_PHASE_FENCE();
+                if (b < 2 && c > b) QLE_BLOCK_FENCE();
 #pragma unroll
                 for (int i = 0; i < 3; ++i) {
 #pragma unroll
@@ -450,7 +464,7 @@ __host__ __device__ __forceinline__ void ekf_update_split(const DevParams<T>& p,
             }
         }
     }
-    QLE_PHASE_FENCE();
+    QLE_UPDATE_FENCE();
     quad::update_inject<SQ, T>(p, x, dx);   // EKF.cpp:486-501
 }
 
