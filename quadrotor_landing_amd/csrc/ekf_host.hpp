@@ -260,6 +260,20 @@ static inline void mr_schedule_extra(qle_batch* h)
     h->e_want = (e > n && period > 1 && period + step < h->mr_Cu && !per_filter_delays) ? e : -1;
 }
 
+// fp64 kernels that keep the covariance split between the LDS and registers (ekf_split.hpp) are launched with 37.5 KiB of dynamic LDS per
+// wave: 150 KiB for a 256-thread workgroup, more than the 64 KiB a launch gets without asking.
+template <typename T> static inline size_t split_lds(const qle_batch* h) { return sizeof(T) == 8 ? (size_t)(h->block / kTile) * kMrLdsPerWave : 0; }
+#define QLE_ASK_LDS(KERNEL, BYTES)                                                                                                    \
+    do {                                                                                                                               \
+        if ((BYTES) > 65536) {                                                                                                         \
+            static bool asked = false;   /* per call site = per instantiation; the attribute is a property of the kernel */             \
+            if (!asked) {                                                                                                              \
+                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(BYTES))); \
+                asked = true;                                                                                                          \
+            }                                                                                                                          \
+        }                                                                                                                              \
+    } while (0)
+
 // ---- kernel launchers, defined and explicitly instantiated for float and double in the tu_*.hip files ----
 int mr_prepare(qle_batch* h);                                                                  // tu_misc
 template <typename T> int launch_step_mr(qle_batch* h, const void* u, const void* z);          // tu_misc: k_step_mr

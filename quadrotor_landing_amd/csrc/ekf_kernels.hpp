@@ -759,6 +759,15 @@ template <typename T> struct MrChain<T, false> {
         });
         store_rec<T, kSW, kXW + W0, W, NT>(dst, i, t);
     }
+    // the whole triangle at once (callers with little else live: k_run_resident, compact records)
+    __device__ __forceinline__ void from_flat(const T (&Pf)[kPW]) { split_from_flat<T>(Pf, top, lo); }
+    template <bool MODIFIES, typename F> __device__ __forceinline__ void with_flat(F&& f)
+    {
+        T P[kPW];
+        split_to_flat<T>(top, lo, P);
+        f(P);
+        if (MODIFIES) split_from_flat<T>(P, top, lo);
+    }
     static constexpr int kTopPart = 84;   // words 0..83: block-rows r, v and the first words of row th (sidx order, ekf_device.hpp)
     __device__ __forceinline__ void load_cov(const T* __restrict__ src, int64_t i)
     {
@@ -1017,9 +1026,21 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
 {
     const int64_t i = batch_block() * blockDim.x + threadIdx.x;
     if (i >= B) return;
-    T x[kXW], P[kPW], u[kUW], un[kUW], accel[3];
+    T x[kXW], u[kUW], un[kUW], accel[3];
     load_rec<T, kSW, 0, kXW>(st, i, x);
-    load_P_any<T>(st, i, P, COMPACT);
+    // fp64: the covariance split between the LDS and registers (ekf_split.hpp; launched with kMrLdsPerWave of dynamic LDS per wave) -- the flat
+    // triangle with the sequential update next to it spilled 0.8-1.2 KB per lane here as it did in k_step_mr; fp32: the flat triangle
+    constexpr bool kSplit = sizeof(T) == 8;
+    MrChain<T, !kSplit> S;      // (fp32 instantiates the block form's type only to keep one declaration; it is not used there)
+    T P[kSplit ? 1 : kPW];
+    if constexpr (kSplit) {
+        S.init();
+        T Pf[kPW];
+        load_P_any<T>(st, i, Pf, COMPACT);
+        S.from_flat(Pf);
+    } else {
+        load_P_any<T>(st, i, P, COMPACT);
+    }
     if (filter_uninitialised(x)) return;
     Noise<T> nz;
     load_noise<T, PFP>(p, pfp, i, nz);
@@ -1031,17 +1052,24 @@ __global__ __launch_bounds__(kBlock) void k_run_resident(DevParams<T> p, T* st, 
         const int32_t s = slot[t];  // wave-uniform
         T zr[kZW];
         if (s >= 0) load_rec<T, kZW, 0, kZW>(zs + (int64_t)s * pitch_z, i, zr);
-        ekf_predict<T>(p, nz, x, P, u, accel);
+        if constexpr (kSplit) {
+            if constexpr (PFP) load_noise<T, PFP>(p, pfp, i, nz);   // read again per tick (L2) rather than 48 registers held through the loop
+            S.predict(p, nz, x, u, accel);
+        } else {
+            ekf_predict<T>(p, nz, x, P, u, accel);
+        }
         if (s >= 0 && zr[7] != T(0)) {
             const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-            ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [](const T (&)[7]) {});
+            if constexpr (kSplit) ekf_update_split<T, DIRECT>(p, nz, x, S.top, S.lo, z, [](const T (&)[7]) {});
+            else ekf_update_emit<T, DIRECT>(p, nz, x, P, z, [](const T (&)[7]) {});
         }
 #pragma unroll
         for (int c = 0; c < kUW; ++c) u[c] = un[c];
         t = tn;
     }
     store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_P_any<T>(st, i, P, COMPACT);
+    if constexpr (kSplit) S.template with_flat<false>([&](const T (&Pf)[kPW]) { store_P_any<T>(st, i, Pf, COMPACT); });
+    else store_P_any<T>(st, i, P, COMPACT);
 }
 
 // Shift the tick origin: subtract `shift` from every filter's last-correction index so that the
@@ -1079,17 +1107,32 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
     T zr[kZW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);
     if (zr[7] == T(0)) return;
-    T x[kXW], P[kPW];
+    T x[kXW];
     load_rec<T, kSW, 0, kXW>(st, i, x);
-    load_P_any<T>(st, i, P, COMPACT);
-    if (filter_uninitialised(x)) return;
     Noise<T> nz;
-    load_noise<T, PFP>(p, pfp, i, nz);
     T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
     T obs[7];
-    ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
-    store_rec<T, kSW, 0, kXW>(st, i, x);
-    store_P_any<T>(st, i, P, COMPACT);
+    if constexpr (sizeof(T) == 8 && !COMPACT) {   // fp64, full records: the split covariance and the batch-form correction (no scratch; see k_run_resident)
+        MrChain<T, false> S;
+        S.init();
+        S.load_cov(st, i);
+        if (filter_uninitialised(x)) return;
+        load_noise<T, PFP>(p, pfp, i, nz);
+        ekf_update_split<T, DIRECT>(p, nz, x, S.top, S.lo, z, [&](const T (&o)[7]) {
+#pragma unroll
+            for (int k = 0; k < 7; ++k) obs[k] = o[k];
+        });
+        store_rec<T, kSW, 0, kXW>(st, i, x);
+        S.template store_cov<0>(st, i);
+    } else {
+        T P[kPW];
+        load_P_any<T>(st, i, P, COMPACT);
+        if (filter_uninitialised(x)) return;
+        load_noise<T, PFP>(p, pfp, i, nz);
+        ekf_update<T, DIRECT>(p, nz, x, P, z, obs);
+        store_rec<T, kSW, 0, kXW>(st, i, x);
+        store_P_any<T>(st, i, P, COMPACT);
+    }
     if (aux_obs) {
 #pragma unroll
         for (int k = 0; k < 7; ++k) aux_obs[i * 7 + k] = obs[k];

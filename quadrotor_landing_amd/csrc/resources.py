@@ -20,7 +20,7 @@ jobs = [("ekf_capi.hip", None)] + [(f"{tu}.hip", t) for tu in ("tu_predict", "tu
 def run(job):
     src, t = job
     cmd = ["/opt/rocm/bin/hipcc"] + FLAGS + ([f"-DQLE_TU_T={t}"] if t else []) + (["-mllvm", "-disable-vector-combine"] if src == "tu_misc.hip" else []) + \
-        (["-mllvm", "-disable-machine-licm"] if (src, t) == ("tu_misc.hip", "double") else []) + [src]
+        (["-mllvm", "-disable-machine-licm"] if (src, t) in (("tu_misc.hip", "double"), ("tu_compact.hip", "double")) else []) + [src]
     return subprocess.run(cmd, cwd=here, capture_output=True, text=True).stderr
 
 

@@ -70,9 +70,10 @@ int run_resident_compact(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t
     const dim3 g = grid_for(h, h->block), b(h->block);
     const T* pfp = (const T*)h->pfp;
     const int64_t pu = (int64_t)(in->pitch_u / h->wsz), pz = (int64_t)(in->pitch_z / h->wsz);
-#define QLE_RES(D, F) hipLaunchKernelGGL((k_run_resident<T, D, F, true>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
-    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_RES(true, true); else QLE_RES(true, false); }
-    else { if (h->pfp_on) QLE_RES(false, true); else QLE_RES(false, false); }
+    const size_t lds = split_lds<T>(h);   // fp64 keeps the covariance split between the LDS and registers here too (k_run_resident)
+#define QLE_RES(D, F) QLE_ASK_LDS((k_run_resident<T, D, F, true>), lds); hipLaunchKernelGGL((k_run_resident<T, D, F, true>), g, b, lds, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) { QLE_RES(true, true); } else { QLE_RES(true, false); } }
+    else { if (h->pfp_on) { QLE_RES(false, true); } else { QLE_RES(false, false); } }
 #undef QLE_RES
     HIP_TRY(hipGetLastError());
     return QLE_OK;

@@ -31,20 +31,8 @@ int launch_step_mr(qle_batch* h, const void* u, const void* z)
     T *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
-    // fp64: the two top block-rows of every filter's covariance live in the LDS for the whole replay (ekf_split.hpp): 37.5 KiB per wave,
-    // 150 KiB of a CU's 160 KiB for a 256-thread workgroup (more than the 64 KiB a launch gets without asking)
-    const size_t lds = sizeof(T) == 8 ? (size_t)(h->block / kTile) * kMrLdsPerWave : 0;
-#define QLE_MR_LAUNCH(D, F)                                                                                                            \
-    do {                                                                                                                               \
-        if (lds > 65536) {                                                                                                             \
-            static bool asked = false;   /* per instantiation; the attribute is a property of the kernel */                           \
-            if (!asked) {                                                                                                              \
-                HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_step_mr<T, D, F>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-                asked = true;                                                                                                          \
-            }                                                                                                                          \
-        }                                                                                                                              \
-        QLE_MR_LAUNCH1(D, F);                                                                                                          \
-    } while (0)
+    const size_t lds = split_lds<T>(h);
+#define QLE_MR_LAUNCH(D, F) do { QLE_ASK_LDS((k_step_mr<T, D, F>), lds); QLE_MR_LAUNCH1(D, F); } while (0)
 #define QLE_MR_LAUNCH1(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, lds, h->stream, p, gp, m, (T*)state_cur(h), (T*)h->mr_u, (T*)h->mr_ckpt, (T*)h->mr_anchor, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
 #ifdef QLE_DEBUG_PTRS   // diagnostic builds only: where every buffer of the launch lies (to place a fault address)
     {
@@ -85,8 +73,9 @@ static int launch_update_d(qle_batch* h, const void* z)
     const dim3 g = grid_for(h, h->block), b(h->block);
     T *st = (T*)state_cur(h), *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-    if (h->pfp_on) hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
-    else hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, 0, h->stream, p, st, (const T*)z, pfp, obs, h->B);
+    const size_t lds = split_lds<T>(h);
+    if (h->pfp_on) { QLE_ASK_LDS((k_update<T, DIRECT, true>), lds); hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, lds, h->stream, p, st, (const T*)z, pfp, obs, h->B); }
+    else { QLE_ASK_LDS((k_update<T, DIRECT, false>), lds); hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, lds, h->stream, p, st, (const T*)z, pfp, obs, h->B); }
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
@@ -108,9 +97,10 @@ int run_resident_t(qle_batch* h, const qle_inputs* in, int64_t t0, int64_t n)
     const dim3 g = grid_for(h, h->block), b(h->block);
     const T* pfp = (const T*)h->pfp;
     const int64_t pu = (int64_t)(in->pitch_u / h->wsz), pz = (int64_t)(in->pitch_z / h->wsz);
-#define QLE_RES(D, F) hipLaunchKernelGGL((k_run_resident<T, D, F>), g, b, 0, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
-    if (h->pub.direct_orien_method) { if (h->pfp_on) QLE_RES(true, true); else QLE_RES(true, false); }
-    else { if (h->pfp_on) QLE_RES(false, true); else QLE_RES(false, false); }
+    const size_t lds = split_lds<T>(h);
+#define QLE_RES(D, F) QLE_ASK_LDS((k_run_resident<T, D, F>), lds); hipLaunchKernelGGL((k_run_resident<T, D, F>), g, b, lds, h->stream, p, (T*)state_cur(h), (const T*)in->u, (const T*)in->z, (const int32_t*)in->d_slot, pu, pz, in->T, t0, n, pfp, h->B)
+    if (h->pub.direct_orien_method) { if (h->pfp_on) { QLE_RES(true, true); } else { QLE_RES(true, false); } }
+    else { if (h->pfp_on) { QLE_RES(false, true); } else { QLE_RES(false, false); } }
 #undef QLE_RES
     HIP_TRY(hipGetLastError());
     return QLE_OK;
