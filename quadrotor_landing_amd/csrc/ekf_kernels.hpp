@@ -1112,10 +1112,16 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
     Noise<T> nz;
     T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
     T obs[7];
-    if constexpr (sizeof(T) == 8 && !COMPACT) {   // fp64, full records: the split covariance and the batch-form correction (no scratch; see k_run_resident)
+    if constexpr (sizeof(T) == 8) {   // fp64: the split covariance and the batch-form correction (no scratch; see k_run_resident)
         MrChain<T, false> S;
         S.init();
-        S.load_cov(st, i);
+        if constexpr (COMPACT) {
+            T Pf[kPW];
+            load_P_compact<T>(st, i, Pf);
+            S.from_flat(Pf);
+        } else {
+            S.load_cov(st, i);
+        }
         if (filter_uninitialised(x)) return;
         load_noise<T, PFP>(p, pfp, i, nz);
         ekf_update_split<T, DIRECT>(p, nz, x, S.top, S.lo, z, [&](const T (&o)[7]) {
@@ -1123,7 +1129,8 @@ __global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict
             for (int k = 0; k < 7; ++k) obs[k] = o[k];
         });
         store_rec<T, kSW, 0, kXW>(st, i, x);
-        S.template store_cov<0>(st, i);
+        if constexpr (COMPACT) S.template with_flat<false>([&](const T (&Pf)[kPW]) { store_P_compact<T>(st, i, Pf); });
+        else S.template store_cov<0>(st, i);
     } else {
         T P[kPW];
         load_P_any<T>(st, i, P, COMPACT);
