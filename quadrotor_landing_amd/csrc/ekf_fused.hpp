@@ -36,6 +36,7 @@
 // have none in either method.
 #pragma once
 
+#include <cmath>
 #include <type_traits>
 
 #include "ekf_device.hpp"
@@ -62,21 +63,45 @@ __host__ __device__ constexpr int block_row_last_word(int b)
     return r;
 }
 
-// Gx = Cc [Cc^T r]x of the conventional orientation method (EKF.cpp:455-458; the expressions of quad::update_noise).
+// Gx = Cc [Cc^T r]x of the conventional orientation method (EKF.cpp:455-458).  Every product-sum is an EXPLICIT fma chain: this function
+// is evaluated several times per tick and in several instantiations (full and compact records) whose results must agree bit for bit, and
+// `a*b - c*d` left to the backend contracts as fma(a, b, -(c*d)) or as fma(-c, d, a*b) depending on what surrounds it.
+template <typename T> __host__ __device__ __forceinline__ T fused_fma(T a, T b, T c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
+__host__ __device__ __forceinline__ float fused_fma(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
 template <typename T>
 __host__ __device__ __forceinline__ void conventional_gx(const T (&x)[16], T (&Gx)[9])
 {
-    const T q[4] = {x[6], x[7], x[8], x[9]};
-    T Cc[9], b[3];
-    quat_to_rot(q, Cc);
+    const T qx = x[6], qy = x[7], qz = x[8], qw = x[9];
+    const T tx = qx + qx, ty = qy + qy, tz = qz + qz;
+    const T twx = tx * qw, twy = ty * qw, twz = tz * qw, txx = tx * qx, tyy = ty * qy, tzz = tz * qz;
+    // Eigen toRotationMatrix (EKF.cpp:429), off-diagonals as one fma each
+    T Cc[9];
+    Cc[0] = T(1) - (tyy + tzz);      Cc[1] = fused_fma(ty, qx, -twz); Cc[2] = fused_fma(tz, qx, twy);
+    Cc[3] = fused_fma(ty, qx, twz);  Cc[4] = T(1) - (txx + tzz);      Cc[5] = fused_fma(tz, qy, -twx);
+    Cc[6] = fused_fma(tz, qx, -twy); Cc[7] = fused_fma(tz, qy, twx);  Cc[8] = T(1) - (txx + tyy);
+    T b[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) b[i] = Cc[i] * x[0] + Cc[3 + i] * x[1] + Cc[6 + i] * x[2];
+    for (int i = 0; i < 3; ++i) b[i] = fused_fma(Cc[6 + i], x[2], fused_fma(Cc[3 + i], x[1], Cc[i] * x[0]));
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const T c0 = Cc[3 * i], c1 = Cc[3 * i + 1], c2 = Cc[3 * i + 2];
-        Gx[3 * i] = c1 * b[2] - c2 * b[1];
-        Gx[3 * i + 1] = c2 * b[0] - c0 * b[2];
-        Gx[3 * i + 2] = c0 * b[1] - c1 * b[0];
+        Gx[3 * i] = fused_fma(c1, b[2], -(c2 * b[1]));
+        Gx[3 * i + 1] = fused_fma(c2, b[0], -(c0 * b[2]));
+        Gx[3 * i + 2] = fused_fma(c0, b[1], -(c1 * b[0]));
     }
 }
 
@@ -168,7 +193,8 @@ __device__ __forceinline__ void ekf_step_fused_z(const DevParams<T>& p, const No
                     for (int kk = 0; kk < 3; ++kk) { v[kk] = Pn[sidx(a, kk)]; v[3 + kk] = Pn[sidx(a, 6 + kk)]; }
                     if (!DIRECT) {
 #pragma unroll
-                        for (int kk = 0; kk < 3; ++kk) v[kk] += v[3] * gx[3 * kk] + v[4] * gx[3 * kk + 1] + v[5] * gx[3 * kk + 2];
+                        for (int kk = 0; kk < 3; ++kk)   // pinned evaluation order (see conventional_gx)
+                            v[kk] += fused_fma(v[5], gx[3 * kk + 2], fused_fma(v[4], gx[3 * kk + 1], v[3] * gx[3 * kk]));
                     }
 #pragma unroll
                     for (int m = 1; m < 6; ++m) {
