@@ -21,6 +21,7 @@
 // rounding, and no 15x6 copy of P G^T in registers.  Every array index below is a compile-time constant after
 // unrolling, so nothing lives in scratch memory.
 #pragma once
+#include <cmath>
 
 #include <hip/hip_runtime.h>
 
@@ -34,6 +35,24 @@ __device__ __forceinline__ double t_atan2(double a, double b) { return atan2(a, 
 __device__ __forceinline__ void t_sincos(float v, float* s, float* c) { sincosf(v, s, c); }
 __device__ __forceinline__ void t_sincos(double v, double* s, double* c) { sincos(v, s, c); }
 
+// An fma the backend cannot re-associate: where one expression is instantiated in several kernels whose results must agree bit for bit,
+// `a*b + c*d` must not be left to contract as fma(a, b, c*d) in one and fma(c, d, a*b) in the other.
+template <typename T> __host__ __device__ __forceinline__ T fused_fma(T a, T b, T c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fma(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
+__host__ __device__ __forceinline__ float fused_fma(float a, float b, float c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_fmaf(a, b, c);
+#else
+    return std::fma(a, b, c);
+#endif
+}
 // Packed storage order of the symmetric 15x15 covariance (120 words).
 //
 // P is 5x5 blocks of 3x3 (r, v, th, ab, wb).  The order serves two kernel families at once:

@@ -66,22 +66,6 @@ __host__ __device__ constexpr int block_row_last_word(int b)
 // Gx = Cc [Cc^T r]x of the conventional orientation method (EKF.cpp:455-458).  Every product-sum is an EXPLICIT fma chain: this function
 // is evaluated several times per tick and in several instantiations (full and compact records) whose results must agree bit for bit, and
 // `a*b - c*d` left to the backend contracts as fma(a, b, -(c*d)) or as fma(-c, d, a*b) depending on what surrounds it.
-template <typename T> __host__ __device__ __forceinline__ T fused_fma(T a, T b, T c)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_fma(a, b, c);
-#else
-    return std::fma(a, b, c);
-#endif
-}
-__host__ __device__ __forceinline__ float fused_fma(float a, float b, float c)
-{
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_fmaf(a, b, c);
-#else
-    return std::fma(a, b, c);
-#endif
-}
 template <typename T>
 __host__ __device__ __forceinline__ void conventional_gx(const T (&x)[16], T (&Gx)[9])
 {

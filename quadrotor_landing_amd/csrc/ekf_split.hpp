@@ -407,7 +407,8 @@ __host__ __device__ __forceinline__ void ekf_update_split(const DevParams<T>& p,
                 t[k] = a < 3 ? top.ld(T_RT + 3 * a + k) : a < 6 ? top.ld(T_VT + 3 * (a - 3) + k) : a < 9 ? lo[L_TT + sym3(a - 6, k)]
                      : a < 12 ? lo[L_TA + 3 * k + (a - 9)] : lo[L_TW + 3 * k + (a - 12)];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) V[a][k] += t[0] * f.Gx[3 * k] + t[1] * f.Gx[3 * k + 1] + t[2] * f.Gx[3 * k + 2];
+            for (int k = 0; k < 3; ++k)   // pinned evaluation order: compact and full records must agree bit for bit
+                V[a][k] += fused_fma(t[2], f.Gx[3 * k + 2], fused_fma(t[1], f.Gx[3 * k + 1], t[0] * f.Gx[3 * k]));
         }
     }
 #pragma unroll
@@ -421,7 +422,7 @@ __host__ __device__ __forceinline__ void ekf_update_split(const DevParams<T>& p,
                 for (int k = 0; k < 3; ++k) {
                     const T pk = a < 3 ? top.ld(T_RT + 3 * a + k) : a < 6 ? top.ld(T_VT + 3 * (a - 3) + k) : a < 9 ? lo[L_TT + sym3(a - 6, k)]
                                : a < 12 ? lo[L_TA + 3 * k + (a - 9)] : lo[L_TW + 3 * k + (a - 12)];
-                    w[k] = pk - (V[a][0] * Cx[0][k] + V[a][1] * Cx[1][k] + V[a][2] * Cx[2][k]);
+                    w[k] = pk - fused_fma(V[a][2], Cx[2][k], fused_fma(V[a][1], Cx[1][k], V[a][0] * Cx[0][k]));
                 }
 #pragma unroll
                 for (int k = 0; k < 3; ++k) V[a][k] = w[k];
