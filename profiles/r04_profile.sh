@@ -74,6 +74,16 @@ timeout -k 10 300 $py bench.py --workload rotors --dtype f64 --no-cpu-baseline -
 timeout -k 10 300 $py bench.py --workload hardware --no-cpu-baseline --no-extras > $O/r04_bench_hardware.json 2>> $R/bench.err
 timeout -k 10 300 $py bench.py --workload hardware --dtype f64 --no-cpu-baseline --no-extras > $O/r04_bench_hardware_f64.json 2>> $R/bench.err
 
+step "soak runs on the final kernels (long timed regions: no non-finite filter, the short runs' rates)"
+timeout -k 10 300 $py bench.py --steps 504000 --warmup 0 --no-cpu-baseline --no-extras > $O/r04_bench_soak.json 2>> $R/bench.err
+timeout -k 10 300 $py bench.py --workload cfg3mr --steps 140000 --warmup 0 --no-cpu-baseline --no-extras > $O/r04_bench_soak_multirate.json 2>> $R/bench.err
+timeout -k 10 300 $py bench.py --workload cfg3mr --dtype f64 --steps 140000 --warmup 0 --no-cpu-baseline --no-extras > $O/r04_bench_soak_multirate_f64.json 2>> $R/bench.err
+timeout -k 10 300 $py bench.py --workload hardware --steps 70000 --warmup 0 --no-cpu-baseline --no-extras > $O/r04_bench_soak_hardware.json 2>> $R/bench.err
+timeout -k 10 300 $py bench.py --workload hardware --dtype f64 --steps 42000 --warmup 0 --no-cpu-baseline --no-extras > $O/r04_bench_soak_hardware_f64.json 2>> $R/bench.err
+timeout -k 10 300 $py bench.py --workload rotors --steps 280000 --warmup 0 --no-cpu-baseline --no-extras > $O/r04_bench_soak_rotors.json 2>> $R/bench.err
+for f in $O/r04_bench_soak*.json; do $py -c "
+import json,sys; d=json.load(open('$f')); print('$f'.split('/')[-1], '%.3e ticks/s' % d['value'], 'steps', d['steps'], 'nonfinite', d['nonfinite_filters'], 'rmse', d.get('rmse_vs_truth',{}).get('position_m'))"; done
+
 step kernel stats
 stats() {  # tag label args...
   tag=$1; label=$2; shift 2
