@@ -38,13 +38,10 @@ OUT_DIR = os.path.dirname(os.path.abspath(__file__))
 # --------------------------------------------------------------------------
 # shims
 # --------------------------------------------------------------------------
-def _install_shims():
-    np.math = math  # PYQH.py uses np.math.{cos,sin,atan2}
-    for name in ("rospy", "geometry_msgs", "geometry_msgs.msg", "sensor_msgs",
-                 "sensor_msgs.msg", "apriltag_ros", "apriltag_ros.msg",
-                 "std_msgs", "std_msgs.msg"):
-        sys.modules[name] = mock.MagicMock()
-    tf_mod = mock.MagicMock()
+def tf_standins():
+    """The five `tf.transformations` functions the reference's two step methods call, as textbook formulas in tf's conventions
+    (quaternions x, y, z, w; Hamilton product; active rotations).  Registers nothing.  tests/test_oracle.py checks them against
+    scipy.spatial.transform.Rotation, an implementation this repository did not write."""
     tft = types.ModuleType("tf.transformations")
 
     def quaternion_matrix(q):
@@ -96,6 +93,17 @@ def _install_shims():
     tft.quaternion_conjugate = quaternion_conjugate
     tft.quaternion_about_axis = quaternion_about_axis
     tft.rotation_matrix = rotation_matrix
+    return tft
+
+
+def _install_shims():
+    np.math = math  # PYQH.py uses np.math.{cos,sin,atan2}
+    for name in ("rospy", "geometry_msgs", "geometry_msgs.msg", "sensor_msgs",
+                 "sensor_msgs.msg", "apriltag_ros", "apriltag_ros.msg",
+                 "std_msgs", "std_msgs.msg"):
+        sys.modules[name] = mock.MagicMock()
+    tf_mod = mock.MagicMock()
+    tft = tf_standins()
     tf_mod.transformations = tft
     sys.modules["tf"] = tf_mod
     sys.modules["tf.transformations"] = tft

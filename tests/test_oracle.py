@@ -552,3 +552,55 @@ def test_synth_restatement_counter_rng_and_sharding():
         np.testing.assert_array_equal(part[k], whole[k][32:64])
     assert np.allclose(np.linalg.norm(whole["z"][..., 3:], axis=-1), 1.0) and np.allclose(np.linalg.norm(whole["truth"][:, 3:], axis=1), 1.0)
     assert abs(np.linalg.norm(whole["u"][..., :3], axis=-1).mean() - 9.81) < 0.5   # specific force ~ g
+
+
+# ------------------------------------------------------------------ conventions against a third-party implementation
+def test_rotation_conventions_against_scipy(golden_dir):
+    """The fixtures under tests/golden were generated by the reference's Python twin with textbook stand-ins for the five
+    `tf.transformations` functions it calls (make_golden.py: `tf` is not installed here), and the C++ text relies on Eigen's
+    quaternion conventions (EKF.cpp:359,367,431,448; QH.cpp:9-58), which the oracle restates.  Neither library is in the image;
+    scipy.spatial.transform.Rotation is, and documents the same conventions (scalar-last x, y, z, w; Hamilton product; active
+    rotation matrices).  Both the stand-ins and the oracle's helpers are held against it here."""
+    import importlib.util
+    from scipy.spatial.transform import Rotation as R
+    spec = importlib.util.spec_from_file_location("_make_golden_for_test", os.path.join(golden_dir, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    tft = mg.tf_standins()
+    ekf_np_mod = ekf_np
+    rng = np.random.default_rng(20260704)
+    tol = 4e-15
+    for k in range(300):
+        q1 = rng.normal(size=4); q1 /= np.linalg.norm(q1)
+        q0 = rng.normal(size=4); q0 /= np.linalg.norm(q0)
+        r1, r0 = R.from_quat(q1), R.from_quat(q0)
+        # tf stand-ins
+        assert np.abs(tft.quaternion_matrix(q1)[:3, :3] - r1.as_matrix()).max() < tol
+        assert np.abs(tft.quaternion_matrix(3.0 * q1)[:3, :3] - r1.as_matrix()).max() < tol      # tf divides by |q|^2
+        assert qclose(tft.quaternion_multiply(q1, q0), (r1 * r0).as_quat(), tol)
+        assert qclose(tft.quaternion_conjugate(q1), r1.inv().as_quat(), tol)
+        axis = rng.normal(size=3)
+        ang = rng.uniform(-math.pi, math.pi) * (1e-9 if k % 10 == 0 else 1.0)
+        rv = ang * axis / np.linalg.norm(axis)
+        assert np.abs(tft.rotation_matrix(ang, axis)[:3, :3] - R.from_rotvec(rv).as_matrix()).max() < tol
+        assert qclose(tft.quaternion_about_axis(ang, axis), R.from_rotvec(rv).as_quat(), tol)
+        # the oracle's helpers (Eigen's toRotationMatrix / operator* / the reference's exp and log)
+        assert np.abs(oracle.quat_to_rot(q1) - r1.as_matrix()).max() < tol
+        assert qclose(oracle.quat_mul(q1, q0), (r1 * r0).as_quat(), tol)
+        assert qclose(oracle.quaternion_exp(rv), R.from_rotvec(rv).as_quat(), tol)
+        qw = q1 if q1[3] > 0 else -q1
+        assert np.abs(oracle.quaternion_log(qw) - R.from_quat(qw).as_rotvec()).max() < 2e-14 * max(1.0, 1.0 / max(qw[3], 1e-3))
+        # the numpy restatement says the same
+        assert np.abs(ekf_np_mod.rot(q1) - r1.as_matrix()).max() < tol
+        assert qclose(ekf_np_mod.qmul(q1, q0), (r1 * r0).as_quat(), tol)
+        assert np.abs(ekf_np_mod.rodrigues(-ang, axis / np.linalg.norm(axis)) - R.from_rotvec(-rv).as_matrix()).max() < tol   # EKF.cpp:394
+    # the observation model's frame chain (EKF.cpp:431-438): q_tv_obs = conj(q_vc * q_ct), r = -R(q_tv_obs) (C_vc r_c + r_v_cv)
+    q_vc = np.array([0.70710678, -0.70710678, 0.0, 0.0]); q_vc /= np.linalg.norm(q_vc)
+    q_ct = rng.normal(size=4); q_ct /= np.linalg.norm(q_ct)
+    r_c = rng.normal(size=3); r_v_cv = np.array([0.1, 0.0, -0.05])
+    q_tv = (R.from_quat(q_vc) * R.from_quat(q_ct)).inv()
+    r_expect = -q_tv.apply(R.from_quat(q_vc).apply(r_c) + r_v_cv)
+    p = oracle.make_params(q_vc=list(q_vc), r_v_cv=list(r_v_cv))
+    r_seed, q_seed = oracle.seed_pose(p, r_c, q_ct)[:2]
+    assert np.abs(np.asarray(r_seed) - r_expect).max() < 1e-14
+    assert qclose(q_seed, q_tv.as_quat(), 1e-14)
