@@ -10,8 +10,11 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_HERE, "libekf_oracle.so")
-_LIB_STRUCT = os.path.join(_HERE, "libekf_oracle_structured.so")
+# QLE_ORACLE_SAN=1 (oracle/sanitize.sh): the AddressSanitizer + UBSan builds under oracle/_san/ instead (made by `make sanitize`)
+_SAN = os.environ.get("QLE_ORACLE_SAN", "0") == "1"
+_LIBDIR = os.path.join(_HERE, "_san") if _SAN else _HERE
+_LIB = os.path.join(_LIBDIR, "libekf_oracle.so")
+_LIB_STRUCT = os.path.join(_LIBDIR, "libekf_oracle_structured.so")
 ORC_MAX_TAGS = 16
 
 _d = C.c_double
@@ -61,6 +64,8 @@ def build(force=False):
     """Compile the C restatement (gcc, seconds).  Building the checker is not using it."""
     src = [os.path.join(_HERE, f) for f in ("ekf_oracle.c", "ekf_oracle.h", "Makefile")]
     stale = (not os.path.exists(_LIB)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in src)
+    if _SAN:
+        return _LIB
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B", "libekf_oracle.so"], check=True)
     return _LIB
@@ -71,6 +76,8 @@ def build_structured(force=False):
     src = [os.path.join(_HERE, "ekf_structured_cpu.cpp"), os.path.join(_HERE, "Makefile")] + \
           [os.path.join(csrc, h) for h in ("ekf_device.hpp", "ekf_quad.hpp", "ekf_fused.hpp", "ekf_packed.hpp", "ekf_split.hpp")]   # the Makefile rule's list
     stale = (not os.path.exists(_LIB_STRUCT)) or any(os.path.getmtime(s) > os.path.getmtime(_LIB_STRUCT) for s in src)
+    if _SAN:
+        return _LIB_STRUCT
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B", "libekf_oracle_structured.so"], check=True)
     return _LIB_STRUCT
