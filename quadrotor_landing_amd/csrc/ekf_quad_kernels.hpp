@@ -32,7 +32,8 @@ constexpr int kLdsFlag = 45;  // bit 0: filter initialised and in range, bit 1: 
 constexpr int kLdsU2 = 46;    // P_rr, P_rt, P_tt (27 words); later dx (15 words)
 constexpr int kLdsPark = 73;  // wave 0's predicted x (16) while the quads work
 constexpr int kLdsPre = 89;   // from waves 1 and 2: dy (6), Gx (9), R_k upper triangle (21), reported observation (7)
-constexpr int kLdsStride = 133;
+constexpr int kLdsZ = 132;    // quarter-tile workgroups: the tag pose (7) of a filter that corrects, from the scalar role to the helper waves
+constexpr int kLdsStride = 141;
 
 // The quads' view of the scalar results: every value is fetched from the filter's LDS record where it is used.
 template <typename T>
@@ -152,11 +153,17 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
     const bool helper_wave = STEP && (w == SM + 1 || w == SM + 2) && l < FPW;   // ticks with tag poses: the two waves after the main one
     const bool helper_first = w == SM + 1;
     T sx[kXW], su[kUW], szr[kZW], sfp[kFW];
-    if ((scalar_wave || helper_wave) && js < B) {
+    // (the helper waves of a quarter-tile workgroup load nothing: they take the predicted x and the tag pose from the LDS behind the
+    // first barrier -- 30 fewer vector memory instructions per workgroup, each of which costs the CU's address unit 50-90 cycles
+    // whatever the number of active lanes (profiles/micro/wave_load_split.hip), and no second and third predict of the nominal state)
+    constexpr bool kHelpersLate = FPW == 16;
+    if ((scalar_wave || (helper_wave && !kHelpersLate)) && js < B) {
         load_rec<T, kUW, 0, kUW, NT>(us, js, su);
         load_rec<T, kSW, 0, kXW, NT>(st, js, sx);
         if (STEP) load_rec<T, kZW, 0, kZW, NT>(zs, js, szr);
         if (PFP) load_rec<T, kFW, 0, kFW, NT>(pfp, js, sfp);
+    } else if (PFP && helper_wave && js < B) {
+        load_rec<T, kFW, 0, kFW, NT>(pfp, js, sfp);
     }
     T L[quad::kList];
     if (in_q && j < 3) quad_load_P<T, 0, 10, NTL>(tb, fq, j, L);
@@ -164,6 +171,71 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
 #pragma unroll
         for (int k = 0; k < quad::kList; ++k) L[k] = T(0);
     }
+
+    // ---- helper roles (ticks with tag poses): what the correction needs of the predicted NOMINAL state only -- the innovation and the
+    // reported observation (first helper wave), Gx and R_k (second) -- for the factor phase behind the SECOND barrier.
+    // A whole-tile workgroup runs them side by side with the scalar role, in front of the first barrier, from their own copies of x, u, z
+    // (its helper waves carry quads as well and would otherwise delay predict_P).  A quarter-tile workgroup runs them BEHIND the first
+    // barrier, beside the quads' predict_P (its helper waves hold no quads), from what the scalar role left in the LDS.
+    // cfg 2 (4 096 fp64 filters): 10.0-10.25 -> 9.75 us per tick (profiles/r04_tuning.md section 9).
+    auto helper_work = [&]() {
+        // the two waves behind the main scalar role's, lane = local filter
+        // INVARIANT (no barrier orders these waves' load of x against wave 0's in-place store of the predicted x): wave 0 stores x
+        // early only for a filter that does NOT correct on this tick (gate refused, mask clear), and everything these waves write for
+        // such a filter -- dy, Gx, R_k, the reported observation in kLdsPre -- is read only where flag bit 1 (corrects) is set.  A torn
+        // or already-predicted x can therefore only produce values nobody reads; any new consumer of kLdsPre must keep to bit 1.
+        T* rec_s = mine;
+        if (js < B) {
+            T (&x)[kXW] = sx;
+            T (&u)[kUW] = su;
+            T (&zr)[kZW] = szr;
+            quad::NoiseV<T> nz;
+            if (PFP) {
+                T (&fp)[kFW] = sfp;
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nz.ab_static[k] = fp[12 + k]; nz.wb_static[k] = fp[15 + k]; }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nz.R[k] = fp[18 + k];
+            } else {
+#pragma unroll
+                for (int k = 0; k < 3; ++k) { nz.ab_static[k] = p.ab_static[k]; nz.wb_static[k] = p.wb_static[k]; }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) nz.R[k] = p.R[k];
+            }
+            bool act;
+            if (kHelpersLate) {   // the scalar role's decision, its predicted x and the tag pose
+                act = ((int)rec_s[kLdsFlag] & 2) != 0;
+                if (act) {
+#pragma unroll
+                    for (int k = 0; k < kXW; ++k) x[k] = rec_s[kLdsPark + k];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) zr[k] = rec_s[kLdsZ + k];
+                }
+            } else {
+                act = !filter_uninitialised(x) && zr[7] != T(0);
+                if (act) quad::predict_nominal<SQ, T>(p, nz, x, u);
+            }
+            if (act) {
+                if (helper_first) {
+                    const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
+                    T dy[6];
+                    quad::update_innovation<SQ, T, DIRECT>(p, x, z, dy, [&](const T (&obs)[7]) {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) rec_s[kLdsPre + 36 + k] = obs[k];
+                    });
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) rec_s[kLdsPre + k] = dy[k];
+                } else {
+                    T Gx[9], Rk[quad::kRkWords];
+                    quad::update_noise<SQ, T, DIRECT>(p, nz, x, Gx, Rk);
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) rec_s[kLdsPre + 6 + k] = Gx[k];
+#pragma unroll
+                    for (int k = 0; k < quad::kRkWords; ++k) rec_s[kLdsPre + 15 + k] = Rk[k];
+                }
+            }
+        }
+    };
 
     // ---- scalar role: nominal state, blocks of F, the decision whether this filter corrects
     if (scalar_wave) {
@@ -224,6 +296,10 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
                 else {   // the predicted nominal state waits in LDS while the quads work (keeps the quad phases' register count down)
 #pragma unroll
                     for (int k = 0; k < kXW; ++k) mine[kLdsPark + k] = x[k];
+                    if (kHelpersLate) {
+#pragma unroll
+                        for (int k = 0; k < 7; ++k) mine[kLdsZ + k] = zr[k];
+                    }
                 }
             }
         }
@@ -232,53 +308,11 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
         // barrier; a vote at the second barrier instead -- __syncthreads_or -- is two barriers)
         const bool any_corr = __ballot(corr) != 0;   // evaluated by every lane of the scalar role, written by one
         if (STEP && l == 0) lds[FPW * kLdsStride] = T(any_corr ? 1 : 0);
-    } else if (helper_wave) {
-        // waves 1 and 2, filter t % 64: what the correction needs of the predicted NOMINAL state only, side by side with wave 0.
-        // INVARIANT (no barrier orders these waves' load of x against wave 0's in-place store of the predicted x): wave 0 stores x
-        // early only for a filter that does NOT correct on this tick (gate refused, mask clear), and everything these waves write for
-        // such a filter -- dy, Gx, R_k, the reported observation in kLdsPre -- is read only where flag bit 1 (corrects) is set.  A torn
-        // or already-predicted x can therefore only produce values nobody reads; any new consumer of kLdsPre must keep to bit 1.
-        T* rec_s = mine;
-        if (js < B) {
-            T (&x)[kXW] = sx;
-            T (&u)[kUW] = su;
-            T (&zr)[kZW] = szr;
-            quad::NoiseV<T> nz;
-            if (PFP) {
-                T (&fp)[kFW] = sfp;
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { nz.ab_static[k] = fp[12 + k]; nz.wb_static[k] = fp[15 + k]; }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) nz.R[k] = fp[18 + k];
-            } else {
-#pragma unroll
-                for (int k = 0; k < 3; ++k) { nz.ab_static[k] = p.ab_static[k]; nz.wb_static[k] = p.wb_static[k]; }
-#pragma unroll
-                for (int k = 0; k < 6; ++k) nz.R[k] = p.R[k];
-            }
-            if (!filter_uninitialised(x) && zr[7] != T(0)) {
-                quad::predict_nominal<SQ, T>(p, nz, x, u);
-                if (helper_first) {
-                    const T z[7] = {zr[0], zr[1], zr[2], zr[3], zr[4], zr[5], zr[6]};
-                    T dy[6];
-                    quad::update_innovation<SQ, T, DIRECT>(p, x, z, dy, [&](const T (&obs)[7]) {
-#pragma unroll
-                        for (int k = 0; k < 7; ++k) rec_s[kLdsPre + 36 + k] = obs[k];
-                    });
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) rec_s[kLdsPre + k] = dy[k];
-                } else {
-                    T Gx[9], Rk[quad::kRkWords];
-                    quad::update_noise<SQ, T, DIRECT>(p, nz, x, Gx, Rk);
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) rec_s[kLdsPre + 6 + k] = Gx[k];
-#pragma unroll
-                    for (int k = 0; k < quad::kRkWords; ++k) rec_s[kLdsPre + 15 + k] = Rk[k];
-                }
-            }
-        }
+    } else if (helper_wave && !kHelpersLate) {
+        helper_work();
     }
     __syncthreads();
+    if (kHelpersLate && helper_wave && lds[FPW * kLdsStride] != T(0)) helper_work();   // (the word: "somebody in this workgroup corrects")
 
     // ---- quad role: P <- F P F^T + Q; the words of a block-row are stored as soon as they are final unless a correction follows
     T* rec = lds + (quad_thread ? lfq : 0) * kLdsStride;
