@@ -409,6 +409,7 @@ __global__ __launch_bounds__(kBlock, WgWaves<T>::value) void kw_tick(DevParams<T
                                                                       int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
 {
     __shared__ T lds[FPW * kLdsStride + 2];   // the per-filter records + the workgroup's "somebody corrects" word
+    QLE_ARGS_EARLY(st, us, zs, B, gridDim.x);
     constexpr int PER = kTile / FPW;
     const int64_t wg = batch_block();
     const int64_t tile = wg / PER;
