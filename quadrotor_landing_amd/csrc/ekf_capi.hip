@@ -301,6 +301,9 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // BELOW 65 536 filters, where 256-thread workgroups leave CUs without work (32 768 filters are 128 of them on 256 CUs): predict tick
     // 7.2 -> 6.5 us at 32 768 fp32 filters, 6.0 -> 4.95 at 16 384, fp64 9.5 -> 7.55 at 16 384 (profiles/r03_tuning.md section 7).
     h->block = (batch >= 262144 || batch < 65536) ? 64 : kBlock;
+    // k_predict<float> with every load in front of the arithmetic: where a SIMD holds one wave (predict_tick, ekf_kernels.hpp); QLE_LOADS_FIRST=0|1 forces
+    h->loads_first = batch <= 65536;
+    if (const char* s = std::getenv("QLE_LOADS_FIRST")) h->loads_first = std::atoi(s) != 0;
     if (const char* s = std::getenv("QLE_BLOCK")) {
         int b = std::atoi(s);
         if (b == 64 || b == 128 || b == 256) h->block = b;

@@ -68,6 +68,7 @@ struct qle_batch {
     void* ring = nullptr;
     void* pfp = nullptr;   // [24 words] per-filter params, wave tiles
     bool pfp_on = false;
+    bool loads_first = false;   // k_predict<float>: every load requested before the arithmetic starts (batches of at most one wave per SIMD)
     bool aux = false;
     void* aux_accel = nullptr;  // AoS [B][3], compute dtype
     void* aux_obs = nullptr;    // AoS [B][7]

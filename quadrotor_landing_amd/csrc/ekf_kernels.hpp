@@ -138,6 +138,15 @@ template <typename... A> __device__ __forceinline__ void args_early(A... a)
 #endif
 }
 #define QLE_ARGS_EARLY(...) args_early(__VA_ARGS__)
+// nothing is scheduled across this point: the loads in front of it are all issued before the arithmetic behind it starts
+#ifndef QLE_LOADS_FIRST_ON
+#define QLE_LOADS_FIRST_ON 1
+#endif
+#if QLE_LOADS_FIRST_ON
+#define QLE_LOADS_FIRST() __builtin_amdgcn_sched_barrier(0)
+#else
+#define QLE_LOADS_FIRST() ((void)0)
+#endif
 __device__ __forceinline__ int64_t batch_block()
 {
 #if QLE_XCD_CHUNK
@@ -354,7 +363,7 @@ __device__ inline bool corner_gate(const GateParams& g, const double (&z)[7])
 // before its first store).  MR (multirate filter): the tick also appends to the history -- the IMU sample goes to its slot
 // of the IMU ring (hist_u, EKF.cpp:254-256) and on checkpoint ticks the new state is copied to its checkpoint slot
 // (hist_ck != nullptr, wave-uniform); see k_step_mr for the history scheme.
-template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false>
+template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false, bool LF = false>
 __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src, T* dst, const T* __restrict__ us,
                                              const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
                                              T* __restrict__ hist_ck, bool ck_cached, int64_t i)
@@ -369,6 +378,13 @@ __device__ __forceinline__ void predict_tick(const DevParams<T>& p, const T* src
     constexpr int NQ = kPW / VW;
     if constexpr (COMPACT) load_P_compact<T, NT>(src, i, P);
     else load_P_quads_desc<T, 0, NQ, NT>(src, i, P);
+    // Every load of the tick is requested before the first instruction that needs one of them: left alone the scheduler issued ten of
+    // the 36 record loads, waited for x and u, ran the first dozen instructions of the nominal predict (they feed the wave-uniform
+    // branch of the half-angle series that ends the block) and only then requested the other 26 quads of the covariance -- one memory
+    // round trip later.  LF is chosen per launch (tu_predict.hip): +1 % where every SIMD holds ONE wave (65 536 filters: 9.39 -> 9.30 us),
+    // nothing below, and -3 % with two waves per SIMD (131 072: 20.8 -> 21.4 us), where the staggered requests are the gentler pattern
+    // for the caches (profiles/r04_tuning.md section 10).
+    if constexpr (LF) QLE_LOADS_FIRST();
     // A filter that is not initialised is left untouched.  No early exit: the compiler would sink the covariance loads below such a
     // branch and every wave would wait for x before it even issues them (+1 us per tick at 65 536 filters, profiles/r02_tuning.md).
     // Instead the lane computes on (with a unit quaternion, so that its arithmetic stays finite) and only its stores are masked.
@@ -438,7 +454,7 @@ __device__ __forceinline__ bool cached_workgroup(int32_t split)
     return split >= 0 ? blockIdx.x < (unsigned)split : ((blockIdx.x >> 3) & 63u) < (unsigned)(-split);
 }
 
-template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false>
+template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false, bool LF = false>
 __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
                                                        T* __restrict__ hist_ck, int64_t B, int32_t split, int32_t ck_cached, int64_t i0)
@@ -447,10 +463,10 @@ __global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevP
     const int64_t i = i0 + batch_block() * blockDim.x + threadIdx.x;   // i0: first filter of this launch (a tick may be launched in chunks)
     if (i >= B) return;
     if (NT == 3) {
-        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
-        else predict_tick<T, PFP, 2, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR, COMPACT, LF>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        else predict_tick<T, PFP, 2, MR, COMPACT, LF>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
     } else {
-        predict_tick<T, PFP, NT, MR, COMPACT>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
+        predict_tick<T, PFP, NT, MR, COMPACT, LF>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
     }
 }
 

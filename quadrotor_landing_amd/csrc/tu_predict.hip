@@ -25,7 +25,10 @@ int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, b
     // QLE_LDS_PAD=bytes (experiments): dynamic LDS the kernel never touches, to cap the workgroups a CU holds (occupancy experiments
     // on the 131 072 ... 524 288-filter plateau, profiles/r03_tuning.md)
     static const size_t lds_pad = [] { const char* s = std::getenv("QLE_LDS_PAD"); return s ? (size_t)std::atoll(s) : (size_t)0; }();
-#define QLE_PRED(F, N, M) for_chunks(h, h->block, [&](dim3 gc, int64_t i0, int64_t end) { hipLaunchKernelGGL((k_predict<T, F, N, M>), gc, b, lds_pad, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, end, h->split, ck_cached, i0); })
+    // "loads first" (predict_tick): the fp32 tick of a batch that gives every SIMD at most one wave
+    const bool lf = sizeof(T) == 4 && h->loads_first;
+#define QLE_PRED_L(F, N, M, L) for_chunks(h, h->block, [&](dim3 gc, int64_t i0, int64_t end) { hipLaunchKernelGGL((k_predict<T, F, N, M, false, L>), gc, b, lds_pad, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, end, h->split, ck_cached, i0); })
+#define QLE_PRED(F, N, M) do { if constexpr (sizeof(T) == 4) { if (lf) QLE_PRED_L(F, N, M, true); else QLE_PRED_L(F, N, M, false); } else QLE_PRED_L(F, N, M, false); } while (0)
 #define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
     const int nt = effective_nt(h);
 #define QLE_PRED_M(M) do { if (nt == 2) QLE_PRED_N(2, M); else if (nt == 1) QLE_PRED_N(1, M); else QLE_PRED_N(0, M); } while (0)
@@ -35,6 +38,7 @@ int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, b
 #undef QLE_PRED_M
 #undef QLE_PRED_N
 #undef QLE_PRED
+#undef QLE_PRED_L
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
