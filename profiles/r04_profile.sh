@@ -131,12 +131,13 @@ QLE_QUAD=0 QLE_TIME_DIRECT=0 timeout -k 10 120 $py profiles/time_kernels.py 6553
 cat $O/r04_kernel_times.jsonl | cut -c1-200
 
 step "per-wave timelines, diagnostic build, and the pk_fma / store-path microbenchmarks"
-for mb in pk_issue store_path; do /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o profiles/micro/$mb profiles/micro/$mb.hip; done
+for mb in pk_issue store_path wave_load_split; do /opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -o profiles/micro/$mb profiles/micro/$mb.hip; done
 QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/r03_scripts/mr_timeline.py 65536 12 > $O/r04_mr_timeline.log 2>&1
 QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/r03_scripts/mr_timeline.py 65536 12 f64 > $O/r04_mr_timeline_f64.log 2>&1
 QLE_LIB=$PWD/quadrotor_landing_amd/libqle_dbg.so timeout -k 10 200 $py profiles/r03_scripts/kw_timeline.py 4096 f64 > $O/r04_kw_timeline.log 2>&1
 timeout -k 10 120 profiles/micro/pk_issue > $O/r04_pk_issue.log 2>&1
 timeout -k 10 60 profiles/micro/store_path > $O/r04_store_path.log 2>&1
+timeout -k 10 60 profiles/micro/wave_load_split > $O/r04_wave_load_split.log 2>&1
 tail -3 $O/r04_mr_timeline.log $O/r04_kw_timeline.log
 
 step "what the ticks after a multirate correction cost (durations by distance from the correcting tick, from the kernel trace above)"
