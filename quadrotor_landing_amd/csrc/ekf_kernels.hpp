@@ -147,15 +147,16 @@ template <typename... A> __device__ __forceinline__ void args_early(A... a)
 #else
 #define QLE_LOADS_FIRST() ((void)0)
 #endif
-__device__ __forceinline__ int64_t batch_block()
+__device__ __forceinline__ int64_t batch_block(unsigned grid)
 {
 #if QLE_XCD_CHUNK
-    const unsigned b = blockIdx.x, n8 = gridDim.x & ~7u;
+    const unsigned b = blockIdx.x, n8 = grid & ~7u;
     return b < n8 ? (int64_t)((b & 7u) * (n8 >> 3) + (b >> 3)) : (int64_t)b;
 #else
     return (int64_t)blockIdx.x;
 #endif
 }
+__device__ __forceinline__ int64_t batch_block() { return batch_block(gridDim.x); }
 
 __device__ __forceinline__ int64_t wave_tile(int64_t i) { return (int64_t)__builtin_amdgcn_readfirstlane((int)(i >> 6)); }
 
@@ -455,12 +456,17 @@ __device__ __forceinline__ bool cached_workgroup(int32_t split)
 }
 
 template <typename T, bool PFP, int NT, bool MR, bool COMPACT = false, bool LF = false>
-__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(DevParams<T> p, const T* src, T* dst, const T* __restrict__ us,
+__global__ __launch_bounds__(kBlock, PredictWaves<T>::value) void k_predict(const T* src, T* dst, const T* __restrict__ us, int64_t B, int64_t i0,
+                                                       int32_t grid_x, int32_t block_x, int32_t split, int32_t ck_cached,
                                                        const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ hist_u,
-                                                       T* __restrict__ hist_ck, int64_t B, int32_t split, int32_t ck_cached, int64_t i0)
+                                                       T* __restrict__ hist_ck, DevParams<T> p)
 {
-    QLE_ARGS_EARLY(src, dst, us, B, i0, gridDim.x, blockDim.x);
-    const int64_t i = i0 + batch_block() * blockDim.x + threadIdx.x;   // i0: first filter of this launch (a tick may be launched in chunks)
+    // Argument order: what the first loads depend on comes first, 14 dwords of it, so that the wave finds them in its SGPRs when it starts
+    // (the translation units are built with -amdgpu-kernarg-preload-count; grid and block size are passed explicitly because the
+    // hidden arguments are not among the preloaded ones) instead of fetching them from the kernel-argument segment -- a memory round
+    // trip in front of every launch's first load.  The parameter block, needed when the first data arrive, comes last.
+    QLE_ARGS_EARLY(src, dst, us, B, i0, grid_x, block_x);
+    const int64_t i = i0 + batch_block((unsigned)grid_x) * block_x + threadIdx.x;   // i0: first filter of this launch (a tick may be launched in chunks)
     if (i >= B) return;
     if (NT == 3) {
         if (cached_workgroup(split)) predict_tick<T, PFP, 0, MR, COMPACT, LF>(p, src, dst, us, pfp, aux_accel, hist_u, hist_ck, ck_cached != 0, i);
@@ -576,13 +582,13 @@ __device__ __forceinline__ void step_tick(const DevParams<T>& p, const GateParam
 }
 
 template <typename T, bool DIRECT, bool PFP, bool GATE, int NT, bool COMPACT = false>
-__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us,
-                                                 const T* __restrict__ zs, const T* __restrict__ pfp,
-                                                 T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split, int64_t i0)
+__global__ __launch_bounds__(kBlock, sizeof(T) == 8 ? 1 : 2) void k_step(T* st, const T* __restrict__ us, const T* __restrict__ zs, int64_t B, int64_t i0,
+                                                 int32_t grid_x, int32_t block_x, int32_t split,   // (argument order: see k_predict)
+                                                 const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
+                                                 int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, DevParams<T> p, GateParams gp)
 {
-    QLE_ARGS_EARLY(st, us, zs, B, i0, gridDim.x, blockDim.x);
-    const int64_t i = i0 + batch_block() * blockDim.x + threadIdx.x;
+    QLE_ARGS_EARLY(st, us, zs, B, i0, grid_x, block_x);
+    const int64_t i = i0 + batch_block((unsigned)grid_x) * block_x + threadIdx.x;
     if (i >= B) return;
     if (NT == 3) {   // see k_predict
         if (cached_workgroup(split)) step_tick<T, DIRECT, PFP, GATE, 0, COMPACT>(p, gp, st, us, zs, pfp, aux_accel, aux_obs, last_corr, flags, i);
@@ -829,14 +835,15 @@ template <typename T> struct MrChain<T, false> {
 };
 
 template <typename T, bool DIRECT, bool PFP>
-__global__ __launch_bounds__(kBlock) void k_step_mr(DevParams<T> p, GateParams gp, MrParams m, T* cur, T* uring, T* ckpt, T* anchor,
-                                                    const T* __restrict__ us, const T* __restrict__ zs, const T* __restrict__ pfp,
+__global__ __launch_bounds__(kBlock) void k_step_mr(T* cur, const T* __restrict__ us, const T* __restrict__ zs, int64_t B, int32_t grid_x, int32_t block_x,
+                                                    int32_t* __restrict__ hist_first, T* uring,   // (argument order: see k_predict; the first loads need these 14 dwords)
+                                                    T* ckpt, T* anchor, const T* __restrict__ pfp,
                                                     const double* __restrict__ stamp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                                    int32_t* __restrict__ hist_first, int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags,
-                                                    double* __restrict__ delay_out, int64_t B)
+                                                    int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags,
+                                                    double* __restrict__ delay_out, DevParams<T> p, GateParams gp, MrParams m)
 {
-    QLE_ARGS_EARLY(cur, uring, ckpt, anchor, us, zs, hist_first, B, gridDim.x, blockDim.x);
-    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
+    QLE_ARGS_EARLY(cur, us, zs, B, grid_x, block_x, hist_first, uring, ckpt, anchor);
+    const int64_t i = batch_block((unsigned)grid_x) * block_x + threadIdx.x;
     if ((i & ~(int64_t)63) >= B) return;             // the whole wave lies beyond the batch (wave-uniform)
     // from here on all 64 lanes stay active (the record arrays are allocated in whole tiles; a lane beyond B sees a zeroed,
     // i.e. not initialised, filter and never touches the per-filter scalar arrays)

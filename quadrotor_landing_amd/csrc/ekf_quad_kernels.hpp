@@ -404,14 +404,14 @@ __device__ __forceinline__ void wg_tick(const DevParams<T>& p, const GateParams&
 // Grid: one 256-thread workgroup per FPW filters (a tile, or a quarter of one).  NT as in k_predict / k_step (3 = cached / streamed split
 // per workgroup).
 template <typename T, bool DIRECT, bool PFP, bool GATE, bool STEP, int NT, int FPW>
-__global__ __launch_bounds__(kBlock, WgWaves<T>::value) void kw_tick(DevParams<T> p, GateParams gp, T* st, const T* __restrict__ us, const T* __restrict__ zs,
+__global__ __launch_bounds__(kBlock, WgWaves<T>::value) void kw_tick(T* st, const T* __restrict__ us, const T* __restrict__ zs, int64_t B, int32_t grid_x, int32_t split,   // (argument order: see k_predict)
                                                                       const T* __restrict__ pfp, T* __restrict__ aux_accel, T* __restrict__ aux_obs,
-                                                                      int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, int64_t B, int32_t split)
+                                                                      int32_t* __restrict__ last_corr, uint8_t* __restrict__ flags, DevParams<T> p, GateParams gp)
 {
     __shared__ T lds[FPW * kLdsStride + 2];   // the per-filter records + the workgroup's "somebody corrects" word
-    QLE_ARGS_EARLY(st, us, zs, B, gridDim.x);
+    QLE_ARGS_EARLY(st, us, zs, B, grid_x);
     constexpr int PER = kTile / FPW;
-    const int64_t wg = batch_block();
+    const int64_t wg = batch_block((unsigned)grid_x);
     const int64_t tile = wg / PER;
     const int f0 = (int)(wg % PER) * FPW;
     if (NT == 3) {

@@ -13,7 +13,7 @@ import sys
 here = os.path.dirname(os.path.abspath(__file__))
 flt = sys.argv[1] if len(sys.argv) > 1 else ""
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause",
-         "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-remove-redundant-endcf=0", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null"]
+         "-fno-hip-fp32-correctly-rounded-divide-sqrt", "-mllvm", "-amdgpu-remove-redundant-endcf=0", "-mllvm", "-amdgpu-kernarg-preload-count=14", "-Rpass-analysis=kernel-resource-usage", "-c", "-o", "/dev/null"]
 jobs = [("ekf_capi.hip", None)] + [(f"{tu}.hip", t) for tu in ("tu_predict", "tu_step", "tu_quad", "tu_misc", "tu_compact") for t in ("float", "double")]
 
 

@@ -14,7 +14,7 @@ int launch_predict_compact(qle_batch* h, const void* u, const void* src, void* d
     const dim3 g = grid_for(h, h->block), b(h->block);
     T* acc = h->aux ? (T*)h->aux_accel : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_PRED(F, N) hipLaunchKernelGGL((k_predict<T, F, N, false, true>), g, b, 0, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, (T*)nullptr, (T*)nullptr, h->B, h->split, 0, (int64_t)0)
+#define QLE_PRED(F, N) hipLaunchKernelGGL((k_predict<T, F, N, false, true>), g, b, 0, h->stream, (const T*)src, (T*)dst, (const T*)u, h->B, (int64_t)0, (int32_t)g.x, (int32_t)b.x, h->split, 0, pfp, acc, (T*)nullptr, (T*)nullptr, p)
 #define QLE_PRED_N(N) do { if (h->pfp_on) QLE_PRED(true, N); else QLE_PRED(false, N); } while (0)
     const int nt = effective_nt(h);
     if (nt == 3) QLE_PRED_N(3); else if (nt == 2) QLE_PRED_N(2); else if (nt == 1) QLE_PRED_N(1); else QLE_PRED_N(0);
@@ -32,7 +32,7 @@ static int launch_step_compact_dg(qle_batch* h, const void* u, const void* z)
     const dim3 g = grid_for(h, h->block), b(h->block);
     T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N, true>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split, (int64_t)0)
+#define QLE_STEP_LAUNCH(F, N) hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N, true>), g, b, 0, h->stream, st, (const T*)u, (const T*)z, h->B, (int64_t)0, (int32_t)g.x, (int32_t)b.x, h->split, pfp, acc, obs, h->last_corr, h->flags, p, gp)
 #define QLE_STEP_N(N) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N); else QLE_STEP_LAUNCH(false, N); } while (0)
     const int nt = effective_nt(h);
     if (nt == 3) QLE_STEP_N(3); else if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);

@@ -33,7 +33,7 @@ int launch_step_mr(qle_batch* h, const void* u, const void* z)
     const double* stamp = (h->have_stamps && h->pub.dynamic_meas_delay) ? h->stamp : nullptr;
     const size_t lds = split_lds<T>(h);
 #define QLE_MR_LAUNCH(D, F) do { QLE_ASK_LDS((k_step_mr<T, D, F>), lds); QLE_MR_LAUNCH1(D, F); } while (0)
-#define QLE_MR_LAUNCH1(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, lds, h->stream, p, gp, m, (T*)state_cur(h), (T*)h->mr_u, (T*)h->mr_ckpt, (T*)h->mr_anchor, (const T*)u, (const T*)z, pfp, stamp, acc, obs, h->hist_first, h->last_corr, h->flags, h->delay_cur, h->B)
+#define QLE_MR_LAUNCH1(D, F) hipLaunchKernelGGL((k_step_mr<T, D, F>), g, b, lds, h->stream, (T*)state_cur(h), (const T*)u, (const T*)z, h->B, (int32_t)g.x, (int32_t)b.x, h->hist_first, (T*)h->mr_u, (T*)h->mr_ckpt, (T*)h->mr_anchor, pfp, stamp, acc, obs, h->last_corr, h->flags, h->delay_cur, p, gp, m)
 #ifdef QLE_DEBUG_PTRS   // diagnostic builds only: where every buffer of the launch lies (to place a fault address)
     {
         const size_t sb = slot_bytes(h);

@@ -27,7 +27,7 @@ int launch_predict_sd(qle_batch* h, const void* u, const void* src, void* dst, b
     static const size_t lds_pad = [] { const char* s = std::getenv("QLE_LDS_PAD"); return s ? (size_t)std::atoll(s) : (size_t)0; }();
     // "loads first" (predict_tick): the fp32 tick of a batch that gives every SIMD at most one wave
     const bool lf = sizeof(T) == 4 && h->loads_first;
-#define QLE_PRED_L(F, N, M, L) for_chunks(h, h->block, [&](dim3 gc, int64_t i0, int64_t end) { hipLaunchKernelGGL((k_predict<T, F, N, M, false, L>), gc, b, lds_pad, h->stream, p, (const T*)src, (T*)dst, (const T*)u, pfp, acc, hu, hc, end, h->split, ck_cached, i0); })
+#define QLE_PRED_L(F, N, M, L) for_chunks(h, h->block, [&](dim3 gc, int64_t i0, int64_t end) { hipLaunchKernelGGL((k_predict<T, F, N, M, false, L>), gc, b, lds_pad, h->stream, (const T*)src, (T*)dst, (const T*)u, end, i0, (int32_t)gc.x, (int32_t)h->block, h->split, ck_cached, pfp, acc, hu, hc, p); })
 #define QLE_PRED(F, N, M) do { if constexpr (sizeof(T) == 4) { if (lf) QLE_PRED_L(F, N, M, true); else QLE_PRED_L(F, N, M, false); } else QLE_PRED_L(F, N, M, false); } while (0)
 #define QLE_PRED_N(N, M) do { if (h->pfp_on) QLE_PRED(true, N, M); else QLE_PRED(false, N, M); } while (0)
     const int nt = effective_nt(h);

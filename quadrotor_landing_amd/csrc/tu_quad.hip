@@ -30,7 +30,7 @@ static int launch_quad_dg(qle_batch* h, const void* u, const void* z)
     const dim3 g((unsigned)(tiles * (kTile / fpw))), b(kBlock);
     T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_QT_LAUNCH_W(F, N, W) hipLaunchKernelGGL((kw_tick<T, DIRECT, F, GATE, STEP, N, W>), g, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, h->B, h->split)
+#define QLE_QT_LAUNCH_W(F, N, W) hipLaunchKernelGGL((kw_tick<T, DIRECT, F, GATE, STEP, N, W>), g, b, 0, h->stream, st, (const T*)u, (const T*)z, h->B, (int32_t)g.x, h->split, pfp, acc, obs, h->last_corr, h->flags, p, gp)
 #define QLE_QT_LAUNCH(F, N) do { if (fpw == 16) QLE_QT_LAUNCH_W(F, N, 16); else QLE_QT_LAUNCH_W(F, N, 64); } while (0)
 #define QLE_QT_N(N) do { if (h->pfp_on) QLE_QT_LAUNCH(true, N); else QLE_QT_LAUNCH(false, N); } while (0)
     // the "split" policy (3) belongs to states larger than the Infinity Cache, where this kernel is never selected (<= 4 096 filters);

@@ -14,7 +14,7 @@ static int launch_step_dg(qle_batch* h, const void* u, const void* z)
     const dim3 b(h->block);
     T *st = (T*)state_cur(h), *acc = h->aux ? (T*)h->aux_accel : (T*)nullptr, *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
-#define QLE_STEP_LAUNCH(F, N) for_chunks(h, h->block, [&](dim3 gc, int64_t i0, int64_t end) { hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), gc, b, 0, h->stream, p, gp, st, (const T*)u, (const T*)z, pfp, acc, obs, h->last_corr, h->flags, end, h->split, i0); })
+#define QLE_STEP_LAUNCH(F, N) for_chunks(h, h->block, [&](dim3 gc, int64_t i0, int64_t end) { hipLaunchKernelGGL((k_step<T, DIRECT, F, GATE, N>), gc, b, 0, h->stream, st, (const T*)u, (const T*)z, end, i0, (int32_t)gc.x, (int32_t)h->block, h->split, pfp, acc, obs, h->last_corr, h->flags, p, gp); })
 #define QLE_STEP_N(N) do { if (h->pfp_on) QLE_STEP_LAUNCH(true, N); else QLE_STEP_LAUNCH(false, N); } while (0)
     const int nt = effective_nt(h);
     if (nt == 3) QLE_STEP_N(3); else if (nt == 2) QLE_STEP_N(2); else if (nt == 1) QLE_STEP_N(1); else QLE_STEP_N(0);
