@@ -36,6 +36,7 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_COPY_GBS = 6290.0       # the same guide's measured float4 streaming-copy rate (79 % of the spec peak)
+IC_GATHER_GBS = 8600.0      # the same guide's measured chip-wide rate of a 38 MB table gathered from the Infinity Cache (reads only)
 
 CFG3 = dict(update_freq=400.0, measurement_freq=30.0, limit_measurement_freq=1, direct_orien_method=1,
             est_bias=1, corner_margin_enbl=1, multirate_ekf=0,
@@ -475,6 +476,10 @@ def main():
                                 "; bytes served " + ("by the Infinity Cache" if pol["served_by"] == "infinity_cache" else "partly by the Infinity Cache") + ": not an HBM fraction, see hbm_frac"),
                      "hbm_frac": p_gbs / HBM_PEAK_GBS if pol["served_by"] == "hbm" else None,
                      "frac_of_measured_copy": p_gbs / HBM_COPY_GBS, "measured_copy_GBs": HBM_COPY_GBS,
+                     # an on-die rate has an on-die yardstick too: the guide's measured Infinity-Cache gather rate (a read-only pattern;
+                     # this kernel reads AND writes its bytes, so this is context, not a bound)
+                     "frac_of_infinity_cache_gather": (p_gbs / IC_GATHER_GBS) if pol["served_by"] == "infinity_cache" else None,
+                     "infinity_cache_gather_GBs": IC_GATHER_GBS if pol["served_by"] == "infinity_cache" else None,
                      "served_by": pol["served_by"],
                      "served_by_note": {"infinity_cache": "the state (%.0f MiB) stays in the 256 MiB Infinity Cache from tick to tick: this rate is an on-die "
                                                           "rate and may exceed the HBM copy rate; see hbm_resident for the HBM-served figure" % (pol["ring_bytes"] / 2 ** 20),
