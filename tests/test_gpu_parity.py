@@ -486,8 +486,8 @@ def test_cfg3_full_size_properties_fp32():
 
 def test_launch_rules_do_not_change_results_large_ragged_batch(monkeypatch, kernel_family):
     """The launch rules chosen from the batch size -- XCD-chunked block map, workgroup size (64 threads from 262 144
-    filters on), cache policy incl. the periodic cached-store tick of small states and the cached/streamed split of large ones -- are
-    invisible in the results:
+    filters on), cache policy incl. the periodic cached-store tick of small states and the cached/streamed split of large ones, the
+    order in which the predict tick requests its loads (every load first up to 65 536 filters) -- are invisible in the results:
     a 262 244-filter batch (ragged: not a multiple of 64, grid not a multiple of 8) and a 65 536-filter shard of the
     same global population agree BIT FOR BIT over 280 ticks, and so does the shard with every rule overridden.
     (The kernel FAMILY is the one rule that changes rounding -- the cooperative kernel fuses the measurement in batch form -- so the
@@ -518,7 +518,8 @@ def test_launch_rules_do_not_change_results_large_ragged_batch(monkeypatch, kern
     if kernel_family == "default":
         monkeypatch.delenv("QLE_QUAD")
     for env in (dict(QLE_NT="0", QLE_BLOCK="64"), dict(QLE_NT="2", QLE_BLOCK="128"), dict(QLE_NT="1", QLE_REFRESH="3"),
-                dict(QLE_NT="3", QLE_SPLIT="-20", QLE_BLOCK="64"), dict(QLE_NT="3", QLE_SPLIT="100")):
+                dict(QLE_NT="3", QLE_SPLIT="-20", QLE_BLOCK="64"), dict(QLE_NT="3", QLE_SPLIT="100"),
+                dict(QLE_LOADS_FIRST="0"), dict(QLE_LOADS_FIRST="1", QLE_NT="0", QLE_BLOCK="64")):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         xo, Po = run(Bs, off)
