@@ -128,6 +128,8 @@ __host__ __device__ inline int64_t word_off(int w, int64_t i, int WT)
 // The kernel arguments the first loads depend on, all requested at the kernel's entry.  Left alone the compiler fetches an argument
 // where it is first needed and waits there: grid size -> (wait) -> block size, batch size -> (wait) -> record pointers -> (wait) ->
 // first load, three scalar-cache misses one after the other in front of every launch's first byte; with this they are one.
+// (The per-tick kernels no longer fetch these arguments at all: they are among the 14 dwords the dispatch preloads into SGPRs, see
+// k_predict; for them this only pins the order, for the others -- k_update, k_run_resident -- it is the single fetch.)
 #ifndef QLE_EARLY_ARGS
 #define QLE_EARLY_ARGS 1
 #endif
