@@ -179,6 +179,8 @@ extern "C" int qle_set_params(qle_batch* h, const qle_params* p)
     // Record layout (ekf_kernels.hpp): est_bias = false without the multirate history keeps only the 9 x 9 pose block of P (compact
     // records, 64 words moved per direction instead of 136) on the batch sizes the lane-per-filter kernels serve; the workgroup-cooperative
     // kernels of the small batches (latency-bound, not byte-bound) and the multirate history work on full records.  QLE_COMPACT=0|1 forces it.
+    // fp32 small batches: the cooperative kernel only where ticks with tag poses are frequent (see qle_create)
+    if (h->quad_auto && h->dtype == QLE_F32 && h->B <= 4096) h->quad = d.upd_per_meas <= 3 ? 1 : 0;
     bool compact = !p->est_bias && !mr && h->quad == 0;
     if (const char* s = std::getenv("QLE_COMPACT")) compact = std::atoi(s) != 0 && !p->est_bias && !mr;
     if (compact != h->compact && h->state_set) {   // a live state changes layout with the parameters
@@ -286,8 +288,15 @@ extern "C" int qle_create(qle_batch** out, int64_t batch, int32_t dtype, int32_t
     // one kernel family runs faster end to end: cfg 3 at 4 096 fp32 filters 4.75 against 5.05 us per tick); from 8 192 filters on the lane
     // kernels win every tick kind in both dtypes (8 192 fp64: 11.9 against 12.5 us with tag poses, 6.3 against 8.05 predict-only; 16 384:
     // 13.25 / 14.3, 7.5 / 9.3) -- profiles/r03_small_family.log.
-    h->quad = batch <= 4096 ? 3 : 0;
-    if (const char* s = std::getenv("QLE_QUAD")) h->quad = std::atoi(s) & 7;
+    // Round 4, after the entry changes of the lane kernels (arguments preloaded, profiles/r04_tuning.md section 10): in fp32 the lane kernel
+    // now wins the predict-only tick of the small batches as well, end to end (cfg 3 schedule at 4 096 fp32 filters: 4.00 us per tick on the
+    // lane kernels alone, 4.11-4.25 with the cooperative kernel on the ticks with tag poses, 4.25-4.29 with it on every tick; 1 024 filters:
+    // 3.93-4.03 / 3.91-3.95 / 4.06-4.13), while a tick WITH tag poses is still faster on the cooperative kernel (6.2 against 6.7 us).  So fp32
+    // keeps it for the ticks with tag poses only, and only where the parameters say they are frequent (qle_set_params: at least every third
+    // tick); fp64 keeps it for every tick (predict-only 5.2 against 5.6 us, with tag poses 9.6 against 11.6).  profiles/r04_small_quad_rule.log
+    h->quad = batch <= 4096 ? (dtype == QLE_F64 ? 3 : 1) : 0;
+    h->quad_auto = true;
+    if (const char* s = std::getenv("QLE_QUAD")) { h->quad = std::atoi(s) & 7; h->quad_auto = false; }
     // Multirate history: a state checkpoint every mr_k ticks: a predict tick streams 136/k extra words, a correction replays
     // (k-1)/2 extra predictions on average.  Measured on cfg 3 with a 12-tick camera latency (profiles/r02_tuning.md): k = 4 / 8 / 16
     // -> predict tick 11.7 / 10.9 / 10.4 us, whole schedule 16.1 / 15.1 / 15.1 us per tick; 16 ships (history 0.6 GB).

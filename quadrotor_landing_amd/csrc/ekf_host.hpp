@@ -55,6 +55,7 @@ struct qle_batch {
     int32_t nt_refresh = 0;   // > 0: nt == 1 and the state is <= 40 MiB: non-temporal stores, cached-store tick every nt_refresh ticks
     int32_t nt = 0;        // cache policy of the hot kernels' state accesses: 0 cached, 1 L2-sized scheme (effective_nt), 2 non-temporal, 3 split
     int64_t chunk = 0;     // > 0: the lane-per-filter single-rate ticks are launched in chunks of this many filters (choose_cache_policy)
+    bool quad_auto = true; // quad follows the rules of qle_create / qle_set_params (false: QLE_QUAD given)
     int32_t quad = 0;      // workgroup-cooperative tick kernel (ekf_quad_kernels.hpp): bit 0 ticks with tag poses, bit 1 predict-only ticks
     size_t wsz = 4;
     qle_params pub;

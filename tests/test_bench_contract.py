@@ -55,8 +55,9 @@ def test_bench_json_contract(extra):
     assert d["nonfinite_filters"] == 0
     assert d["repeats"] >= 1 and abs(d["region_ms"]["median"] - d["ms_per_step"] * 42) < 1e-9
     assert rf["served_by"] in ("infinity_cache", "hbm", "split") and abs(rf["frac_of_measured_copy"] - rf["achieved"] / 6290.0) < 1e-12
-    # 4 096 filters: the workgroup-cooperative kernel takes every single-rate tick at this size (quarter-tile workgroups)
-    want_kernel = {"": "kw_tick<float,predict>", "cfg5": "kw_tick<float,predict>", "cfg3mr": "k_predict<float,MR>",
+    # 4 096 filters: in fp64 the workgroup-cooperative kernel takes every single-rate tick at this size (quarter-tile workgroups); in fp32
+    # only the ticks with tag poses, and only on a cadence that has them at least every third tick (cfg 3 / cfg 5: every 14th -> lane kernels)
+    want_kernel = {"": "k_predict<float>", "cfg5": "k_predict<float>+per-filter-params", "cfg3mr": "k_predict<float,MR>",
                    "cfg2": "kw_tick<double,step>", "rotors": "k_predict<float,MR>", "hardware": "k_step_mr<float>"}[extra[1] if extra else ""]
     if "f64" in extra:
         want_kernel = want_kernel.replace("float", "double")

@@ -132,11 +132,17 @@ def test_changing_est_bias_on_a_live_handle_converts_the_records(monkeypatch):
 
 
 def test_default_rule_picks_compact_records_above_4096_filters(monkeypatch):
+    """Compact records wherever the lane-per-filter kernels serve every tick: above 4 096 filters, and since round 4 also on the small fp32
+    batches whose cadence has a tag pose less often than every third tick (the cooperative kernel keeps only the frequent-correction
+    cadences there, and every small fp64 batch)."""
     monkeypatch.delenv("QLE_COMPACT", raising=False)
     monkeypatch.delenv("QLE_QUAD", raising=False)
-    for B, est_bias, mr, want in ((32768, 0, 0, 64), (8192, 0, 0, 64), (32768, 1, 0, 136), (32768, 0, 1, 136), (4096, 0, 0, 136)):
-        ekf = qla.BatchedRelativePoseEKF(B, "f32", params=qla.make_params(**dict(NOBIAS, est_bias=est_bias, multirate_ekf=mr)))
-        assert ekf.policy()["record_words"] == want, (B, est_bias, mr)
+    for B, dtype, est_bias, mr, mfreq, want in ((32768, "f32", 0, 0, 30.0, 64), (8192, "f32", 0, 0, 30.0, 64), (32768, "f32", 1, 0, 30.0, 136),
+                                                (32768, "f32", 0, 1, 30.0, 136), (4096, "f32", 0, 0, 30.0, 64), (4096, "f32", 0, 0, 400.0, 136),
+                                                (4096, "f64", 0, 0, 30.0, 136), (4096, "f32", 1, 0, 30.0, 136)):
+        ekf = qla.BatchedRelativePoseEKF(B, dtype, params=qla.make_params(**dict(NOBIAS, est_bias=est_bias, multirate_ekf=mr, measurement_freq=mfreq)))
+        assert ekf.policy()["record_words"] == want, (B, dtype, est_bias, mr, mfreq)
+        assert ekf.policy()["coop_ticks"] == (0 if B > 4096 or mr else (3 if dtype == "f64" else (1 if mfreq == 400.0 else 0))), (B, dtype, mfreq)
         ekf.close()
 
 
