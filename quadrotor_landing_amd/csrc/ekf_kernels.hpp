@@ -129,7 +129,7 @@ __host__ __device__ inline int64_t word_off(int w, int64_t i, int WT)
 // where it is first needed and waits there: grid size -> (wait) -> block size, batch size -> (wait) -> record pointers -> (wait) ->
 // first load, three scalar-cache misses one after the other in front of every launch's first byte; with this they are one.
 // (The per-tick kernels no longer fetch these arguments at all: they are among the 14 dwords the dispatch preloads into SGPRs, see
-// k_predict; for them this only pins the order, for the others -- k_update, k_run_resident -- it is the single fetch.)
+// k_predict; for them this only pins the order, for k_run_resident -- one launch per run -- it is the single fetch.)
 #ifndef QLE_EARLY_ARGS
 #define QLE_EARLY_ARGS 1
 #endif
@@ -1141,11 +1141,11 @@ __global__ void k_upds_since(const T* __restrict__ st, const int32_t* __restrict
 
 // Stand-alone correction (correction_step, EKF.cpp:417-502) where mask != 0.
 template <typename T, bool DIRECT, bool PFP, bool COMPACT = false>
-__global__ __launch_bounds__(kBlock) void k_update(DevParams<T> p, T* __restrict__ st, const T* __restrict__ zs,
-                                                   const T* __restrict__ pfp, T* __restrict__ aux_obs, int64_t B)
+__global__ __launch_bounds__(kBlock) void k_update(T* __restrict__ st, const T* __restrict__ zs, int64_t B, int32_t grid_x, int32_t block_x,   // (argument order: see k_predict)
+                                                   const T* __restrict__ pfp, T* __restrict__ aux_obs, DevParams<T> p)
 {
-    QLE_ARGS_EARLY(st, zs, B, gridDim.x, blockDim.x);
-    const int64_t i = batch_block() * blockDim.x + threadIdx.x;
+    QLE_ARGS_EARLY(st, zs, B, grid_x, block_x);
+    const int64_t i = batch_block((unsigned)grid_x) * block_x + threadIdx.x;
     if (i >= B) return;
     T zr[kZW];
     load_rec<T, kZW, 0, kZW>(zs, i, zr);

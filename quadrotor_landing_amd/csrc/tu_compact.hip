@@ -56,7 +56,7 @@ int launch_update_compact(qle_batch* h, const void* z)
     T *st = (T*)state_cur(h), *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     const size_t lds = split_lds<T>(h);
-#define QLE_UPD(D, F) QLE_ASK_LDS((k_update<T, D, F, true>), lds); hipLaunchKernelGGL((k_update<T, D, F, true>), g, b, lds, h->stream, p, st, (const T*)z, pfp, obs, h->B)
+#define QLE_UPD(D, F) QLE_ASK_LDS((k_update<T, D, F, true>), lds); hipLaunchKernelGGL((k_update<T, D, F, true>), g, b, lds, h->stream, st, (const T*)z, h->B, (int32_t)g.x, (int32_t)b.x, pfp, obs, p)
     if (h->pub.direct_orien_method) { if (h->pfp_on) { QLE_UPD(true, true); } else { QLE_UPD(true, false); } }
     else { if (h->pfp_on) { QLE_UPD(false, true); } else { QLE_UPD(false, false); } }
 #undef QLE_UPD

@@ -74,8 +74,8 @@ static int launch_update_d(qle_batch* h, const void* z)
     T *st = (T*)state_cur(h), *obs = h->aux ? (T*)h->aux_obs : (T*)nullptr;
     const T* pfp = (const T*)h->pfp;
     const size_t lds = split_lds<T>(h);
-    if (h->pfp_on) { QLE_ASK_LDS((k_update<T, DIRECT, true>), lds); hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, lds, h->stream, p, st, (const T*)z, pfp, obs, h->B); }
-    else { QLE_ASK_LDS((k_update<T, DIRECT, false>), lds); hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, lds, h->stream, p, st, (const T*)z, pfp, obs, h->B); }
+    if (h->pfp_on) { QLE_ASK_LDS((k_update<T, DIRECT, true>), lds); hipLaunchKernelGGL((k_update<T, DIRECT, true>), g, b, lds, h->stream, st, (const T*)z, h->B, (int32_t)g.x, (int32_t)b.x, pfp, obs, p); }
+    else { QLE_ASK_LDS((k_update<T, DIRECT, false>), lds); hipLaunchKernelGGL((k_update<T, DIRECT, false>), g, b, lds, h->stream, st, (const T*)z, h->B, (int32_t)g.x, (int32_t)b.x, pfp, obs, p); }
     HIP_TRY(hipGetLastError());
     return QLE_OK;
 }
